@@ -1,0 +1,238 @@
+/*
+ * transcodon_hip.h -- C ABI of libtranscodon_hip.so (MI355X / gfx950).
+ *
+ * The reference (guyuehuo/TransCodon) is pure Python/PyTorch and has no FFI of
+ * its own; every entry point below therefore cites the reference Python
+ * lines whose arithmetic it replaces.  The host-side mirror of the reference's
+ * Python classes (transcodon_amd/) binds these symbols with ctypes.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers unless a
+ *    parameter says "host";
+ *  - every function returns 0 on success or a negative TC_E* code and never
+ *    throws; tc_last_error() gives the message of the calling thread's last
+ *    failure;
+ *  - nothing is allocated or freed on the device: scratch comes in through
+ *    the caller's workspace (tc_workspace_bytes);
+ *  - launches are asynchronous on `stream` (a hipStream_t passed as void*);
+ *    calls on different streams may run concurrently as long as their output
+ *    and workspace buffers do not overlap;
+ *  - activations are row-major [rows, features]; token row index = b*T + t.
+ */
+#ifndef TRANSCODON_HIP_H
+#define TRANSCODON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TC_VERSION 100
+
+/* status codes */
+#define TC_OK 0
+#define TC_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
+#define TC_ELAUNCH (-2)  /* HIP launch or runtime error */
+#define TC_ENOSPC (-3)   /* workspace too small */
+
+/* element types */
+#define TC_F32 0
+#define TC_BF16 1
+
+/* GEMM epilogues */
+#define TC_EPI_BIAS 0            /* out = A W^T + b                                  */
+#define TC_EPI_BIAS_GELU 1       /* out = gelu_erf(A W^T + b)                        */
+#define TC_EPI_BIAS_RESIDUAL 2   /* out_f32 = residual_f32 + A W^T + b               */
+#define TC_EPI_QKV_ROPE 3        /* fused q/k/v projection, q scale, RoPE on q and k */
+
+int tc_version(void);
+const char *tc_last_error(void);
+
+/*
+ * Token + species embedding gather with pad zeroing.
+ *   x[b*T+t, :] = (tok_table[tokens[b,t]] + species_table[species[b]]) * (tokens[b,t] != pad_idx)
+ * Replaces transcodon/model.py:178-206 (embed_tokens, species_embedding added at
+ * every position, multiplication by 1 - padding_mask).
+ * tokens int32 [B,T]; species int32 [B]; tables f32; x f32 [B*T,E].
+ * pad_flags (optional, may be NULL): uint8 [B*T], 1 where the token is padding.
+ * Token / species ids out of range are reported through *bad_index (optional
+ * device int32, set to 1) and produce a zero row instead of an out-of-bounds read.
+ */
+int tc_embed_fwd(const int32_t *tokens, const int32_t *species, const float *tok_table,
+                 const float *species_table, float *x, uint8_t *pad_flags, int32_t *bad_index,
+                 int B, int T, int E, int vocab, int n_species, int pad_idx, void *stream);
+
+/*
+ * Row LayerNorm with affine terms, biased variance, fp32 statistics.
+ * Replaces torch.nn.LayerNorm(E, eps) as used by ESM1bLayerNorm
+ * (transcodon/modules.py:27-41; call sites modules.py:87,100, model.py:232).
+ * x f32 [M,E]; gamma/beta f32 [E]; out_f32 and/or out_bf16 [M,E] (either may be NULL).
+ */
+int tc_layernorm_fwd(const float *x, const float *gamma, const float *beta, float *out_f32,
+                     void *out_bf16, int M, int E, float eps, void *stream);
+
+/*
+ * out[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]) on the matrix cores.
+ * dtype TC_BF16: A, W bf16, fp32 accumulate (mfma_f32_16x16x32_bf16);
+ * dtype TC_F32 : A, W f32, exact f32 multiply-add chain (mfma_f32_16x16x4_f32).
+ * Replaces the nn.Linear calls of the encoder: q/k/v/out projections
+ * (transcodon/multihead_attention.py:262-265,399), fc1+gelu and fc2
+ * (transcodon/modules.py:17-24,101-103), head dense layers (modules.py:155-156,173-174).
+ *   TC_EPI_BIAS / TC_EPI_BIAS_GELU : out has element type `dtype`, leading dimension ldo.
+ *   TC_EPI_BIAS_RESIDUAL           : out and residual are f32 [M,N] (may alias).
+ *   TC_EPI_QKV_ROPE                : N = 3*E; columns [0,E) are q, [E,2E) k, [2E,3E) v;
+ *       q = (A Wq^T + bq) * q_scale; q and k are rotated pairwise (2i,2i+1) inside each
+ *       head of head_dim columns by the angle table rope_cos/rope_sin f32
+ *       [T, head_dim/2] at position (row mod T)
+ *       (multihead_attention.py:265,358-360; rotary-embedding-torch 0.8.6).
+ * Requirements: N % 128 == 0, K % 64 == 0 (bf16) or K % 32 == 0 (f32), lda >= K, 16-byte
+ * aligned pointers.
+ */
+int tc_gemm(int dtype, int epilogue, const void *A, int lda, const void *W, const float *bias,
+            const float *residual, void *out, int ldo, int M, int N, int K, float q_scale,
+            const float *rope_cos, const float *rope_sin, int T, int head_dim, void *stream);
+
+/*
+ * Key-validity bit masks for the attention kernel: bit j of words[b*nw + w] is 1
+ * when key 64*w + j of sequence b exists (< T) and is not padding.
+ * Replaces the key_padding_mask plumbing of transcodon/model.py:178,219-220 and
+ * multihead_attention.py:373-379.  pad_flags uint8 [B,T]; words uint64 [B, ceil(T/64)].
+ */
+int tc_key_mask_words(const uint8_t *pad_flags, uint64_t *words, int B, int T, void *stream);
+
+/*
+ * Fused multi-head self-attention forward (no score matrix in memory):
+ *   out[b,t,h*D:(h+1)*D] = softmax_fp32(q_h k_h^T masked with -inf at padded keys) v_h
+ * with q already scaled and q,k already rotated.  Replaces
+ * transcodon/multihead_attention.py:362-398 (bmm, masked_fill -inf, fp32 softmax, bmm,
+ * head concat).  qkv [B*T, ldq] holds q at column 0, k at column E, v at column 2E
+ * (E = H*D); out [B*T, E]; element type `dtype`.  key_words from tc_key_mask_words, or
+ * NULL when no key is padded.  D must be 64.
+ */
+int tc_attn_fwd(int dtype, const void *qkv, int ldq, const uint64_t *key_words, void *out, int B,
+                int T, int H, int D, void *stream);
+
+/*
+ * Pre-softmax attention scores for need_head_weights=True callers:
+ *   scores[b,h,i,j] = q_h[i] . k_h[j]   (-inf where key j is padding), f32 [B,H,T,T].
+ * Replaces transcodon/multihead_attention.py:362-379,400-403.
+ */
+int tc_attn_scores(int dtype, const void *qkv, int ldq, const uint8_t *pad_flags, float *scores,
+                   int B, int T, int H, int D, void *stream);
+
+/*
+ * Output heads after the dense+gelu GEMM: per row LayerNorm then a thin projection.
+ *   out[m, v] = sum_e LN(g[m, col0 + e]) * W[v, e] + bias[v],  v < V <= 16
+ * Replaces transcodon/modules.py:157-159 (RobertaLMHead, tied weight) and :175-177
+ * (RNA_2D_RobertaLMHead; pass bias = out_proj.bias + bias).
+ * g has element type `dtype`, leading dimension ldg; W f32 [V,E]; out f32 [M,V].
+ */
+int tc_head_logits_fwd(int dtype, const void *g, int ldg, int col0, const float *gamma,
+                       const float *beta, const float *W, const float *bias, float *out, int M,
+                       int E, int V, float eps, void *stream);
+
+/*
+ * Greedy synonymous-codon decode.  For amino acid i of sequence s the three logit rows
+ * are logits[(row0[s] + 3*i + j) * ldl + 0..9], j = 0..2.  score(codon) = double product,
+ * started at 1.0, of the fp32 softmax (over all 10 symbols) probabilities of its bases;
+ * the first codon, in the reference's table order, with a strictly larger score wins.
+ * Replaces the triple Python loop of transcodon/infer_utr.py:98-133.
+ *   aa      uint8 [n_aa_total]   amino-acid codes: index into "FLIMVPTAY_HQNKDECWRSG"
+ *   aa_off  int32 [n_seq+1]      prefix offsets of each sequence's residues in `aa`
+ *   row0    int32 [n_seq]        logits row of the first CDS base of each sequence
+ *   bases   uint8 [3*n_aa_total] output, ASCII 'A','U','C','G'
+ */
+int tc_codon_decode(const float *logits, int ldl, const uint8_t *aa, const int32_t *aa_off,
+                    const int32_t *row0, uint8_t *bases, int n_seq, int n_aa_total, void *stream);
+
+/*
+ * Mean cross-entropy with ignore_index = -100 over rows of thin logits, forward and
+ * (optionally) gradient.  Replaces nn.CrossEntropyLoss(reduction='mean',
+ * ignore_index=-100) of pretraining.py:54-55,109-112,124-127.
+ *   logits f32 [M,V]; labels int32 [M]; loss_sum f32[1] and count int32[1] are ACCUMULATED
+ *   (zero them first); dlogits f32 [M,V] (may be NULL) receives
+ *   (softmax - onehot) * grad_scale for counted rows and 0 elsewhere.
+ */
+int tc_ce_loss_fwd_bwd(const float *logits, const int32_t *labels, float *loss_sum,
+                       int32_t *count, float *dlogits, float grad_scale, int M, int V,
+                       void *stream);
+
+/* ---- whole-encoder convenience (one call per forward) ---------------------------- */
+
+typedef struct tc_layer_weights {
+    const float *ln1_g, *ln1_b;   /* layers.i.self_attn_layer_norm                    */
+    const void *w_qkv;            /* [3E,E] rows: q_proj, k_proj, v_proj (dtype)      */
+    const float *b_qkv;           /* [3E]                                             */
+    const void *w_o;              /* [E,E]  self_attn.out_proj                        */
+    const float *b_o;
+    const float *ln2_g, *ln2_b;   /* layers.i.final_layer_norm                        */
+    const void *w_fc1;            /* [F,E]                                            */
+    const float *b_fc1;
+    const void *w_fc2;            /* [E,F]                                            */
+    const float *b_fc2;
+    const float *rope_cos, *rope_sin; /* f32 [T_table, D/2] for this layer's rope.freqs */
+} tc_layer_weights;
+
+typedef struct tc_encoder_desc {
+    int32_t dtype;                /* TC_BF16 or TC_F32: element type of GEMM operands  */
+    int32_t num_layers, E, F, H, vocab, n_species, n_struct, pad_idx;
+    int32_t rope_table_len;       /* rows in every rope_cos/rope_sin table (>= T)      */
+    float ln_eps;
+    const float *tok_table;       /* embed_tokens.weight [vocab,E] f32                 */
+    const float *species_table;   /* species_embedding.weight [n_species,E] f32        */
+    const tc_layer_weights *layers; /* host array [num_layers]                          */
+    const float *lnf_g, *lnf_b;   /* emb_layer_norm_after                              */
+    const void *w_heads;          /* [2E,E] rows: lm_head.dense, structure_linear.dense */
+    const float *b_heads;         /* [2E]                                              */
+    const float *lm_ln_g, *lm_ln_b;      /* lm_head.layer_norm                          */
+    const float *lm_bias;                /* lm_head.bias [vocab] (weight = tok_table)   */
+    const float *st_ln_g, *st_ln_b;      /* structure_linear.layer_norm                 */
+    const float *st_w;                   /* structure_linear.out_proj.weight [n_struct,E] */
+    const float *st_bias;                /* out_proj.bias + structure_linear.bias        */
+} tc_encoder_desc;
+
+/* Bytes of device workspace tc_encoder_forward needs for B sequences of T tokens. */
+size_t tc_workspace_bytes(const tc_encoder_desc *desc, int B, int T);
+
+/*
+ * ProteinBertModel.forward (transcodon/model.py:175-259) for a padded batch:
+ * embedding -> num_layers x pre-LN TransformerLayer (modules.py:83-105) -> final
+ * LayerNorm -> LM head and structure head.
+ *   tokens int32 [B,T], species int32 [B]                       (device)
+ *   logits f32 [B*T,vocab]; struct_logits f32 [B*T,n_struct] or NULL;
+ *   rep_last f32 [B*T,E] or NULL  (post emb_layer_norm_after states, model.py:232-237);
+ *   rep_layer / rep_out: optional host arrays of n_rep layer indices (0..num_layers-1,
+ *   0 = embedding output) and matching device f32 [B*T,E] buffers for
+ *   representations of other layers (model.py:210-211,226-227).
+ *   status int32 [1] device (optional): set to 1 if a token/species id was out of range.
+ * desc and desc->layers are read on the host during the call only.
+ */
+int tc_encoder_forward(const tc_encoder_desc *desc, const int32_t *tokens, const int32_t *species,
+                       int B, int T, float *logits, float *struct_logits, float *rep_last,
+                       int n_rep, const int32_t *rep_layer, float *const *rep_out,
+                       int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- per-kernel timing for roofline reports -------------------------------------- */
+#define TC_PROF_GEMM 0
+#define TC_PROF_ATTN 1
+#define TC_PROF_LAYERNORM 2
+#define TC_PROF_EMBED 3
+#define TC_PROF_HEAD 4
+#define TC_PROF_DECODE 5
+#define TC_PROF_NKINDS 6
+/*
+ * When enabled, every launch of the selected kernel families is bracketed by HIP
+ * events on its own stream.  tc_prof_collect synchronises those events and returns, per
+ * kind, the launch count, the summed device time in milliseconds and the summed
+ * algorithmic work (flops for GEMM/ATTN, bytes for the others) since the last reset.
+ */
+int tc_prof_enable(int enabled);
+int tc_prof_reset(void);
+int tc_prof_collect(int kind, int64_t *launches, double *ms_total, double *work_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRANSCODON_HIP_H */

@@ -1,0 +1,106 @@
+"""Host-side logic and the C-ABI surface, no GPU needed."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+import transcodon_amd as ta
+from oracle import transcodon_ref as O
+from transcodon_amd import _lib, infer_utr, ops
+from transcodon_amd.sequence import (CodonSequence, CodonSequence_infer, WithUtr_CodonSequence,
+                                     WithUtr_CodonSequence_infer)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "transcodon_hip.h")).read()
+    declared = set(re.findall(r"\b(tc_[a-z0-9_]+)\s*\(", header))
+    declared -= {"tc_layer_weights", "tc_encoder_desc"}
+    assert len(declared) >= 15
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert set(_lib.EXPORTED_SYMBOLS) == declared
+    assert _lib.load().tc_version() == 100
+
+
+def test_alphabet_matches_reference_facts():
+    a = ta.Alphabet.from_architecture("CodonModel")
+    assert a.all_toks == O.ALL_TOKS
+    assert (a.padding_idx, a.mask_idx, a.cls_idx, a.eos_idx, a.unk_idx) == (1, 9, 0, 2, 3)
+    assert not a.prepend_bos and not a.append_eos
+    assert len(ta.ORGANISM2ID) == 1438 and ta.ORGANISM2ID["Arabidopsis thaliana"] == 0
+    assert sorted(ta.ORGANISM2ID.values()) == list(range(1438))
+    with pytest.raises(ValueError):
+        ta.Alphabet.from_architecture("nope")
+
+
+def test_tokeniser_against_golden_rows(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "full_testcsv_decode.json")))
+    import csv
+    for r in g["rows"]:
+        aa_like = "".join(O.CODON2AA[r["noutr"]["rna"][i:i + 3]]
+                          for i in range(0, len(r["noutr"]["rna"]), 3)).replace("#", "_")
+        assert infer_utr.AA_tokenize(aa_like) == r["template"] == O.aa_tokenize(aa_like)
+        ids = infer_utr.tokenize(CodonSequence_infer(r["template"]))[0].tolist()
+        assert ids == O.encode(O.token_strings("false", r["template"]))
+        assert len(ids) == r["noutr"]["T"]
+    utr = "ACGTTGCA AC"
+    ids = infer_utr.tokenize(WithUtr_CodonSequence_infer(utr, "AU*GC*"))[0].tolist()
+    assert ids == O.encode(O.token_strings(utr, "AU*GC*"))
+    assert ids == [0, 5, 7, 8, 6, 6, 8, 7, 5, 5, 7, 4, 5, 6, 9, 8, 7, 9, 2]
+    assert WithUtr_CodonSequence("AT", "GC").seq == "<cls> A U <sep> G C <eos>"
+    assert CodonSequence("ignored", "ATG").tokens == ["<cls>", "A", "U", "G", "<eos>"]
+    with pytest.raises(KeyError):
+        infer_utr.AA_tokenize("MXK_")
+    with pytest.raises(KeyError):
+        ta.Alphabet.from_architecture("CodonModel").encode("A N G")
+
+
+def test_batch_converter_pads_right():
+    bc = ta.Alphabet.from_architecture("CodonModel").get_batch_converter()
+    _, strs, toks = bc([("a", "<cls> A U <eos>"), ("b", "<cls> G <mask> C A <eos>")])
+    assert toks.dtype == torch.int64 and toks.shape == (2, 6)
+    assert toks[0].tolist() == [0, 5, 6, 2, 1, 1]
+    assert toks[1].tolist() == [0, 8, 9, 7, 5, 2]
+
+
+def test_amino_acid_codes_follow_decode_table():
+    assert ops.AA_ORDER == "".join(O.AA2CODONS.keys())
+    assert ops.encode_amino_acids("FG_") == bytes([0, 20, 9])
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
+    m = ta.ProteinBertModel(ta.default_args(num_layers=2, embed_dim=128, ffn_embed_dim=512,
+                                            attention_heads=2, species_vocab_size=16),
+                            ta.Alphabet.from_architecture("CodonModel"))
+    keys = set(m.state_dict())
+    want = {k for k in ref if not k.startswith("layers.") or k.split(".")[1] in ("0", "1")}
+    assert keys == want
+    assert m.lm_head.weight is m.embed_tokens.weight
+
+
+def test_no_cpu_fallback():
+    m = ta.ProteinBertModel(ta.default_args(num_layers=1, embed_dim=128, ffn_embed_dim=512,
+                                            attention_heads=2, species_vocab_size=4),
+                            ta.Alphabet.from_architecture("CodonModel"))
+    with pytest.raises(_lib.HipLibraryError):
+        with torch.no_grad():
+            m(torch.zeros(1, 8, dtype=torch.long), torch.zeros(1, dtype=torch.long))
+    with pytest.raises(_lib.HipLibraryError):
+        ops.layernorm(torch.zeros(4, 128), torch.ones(128), torch.zeros(128))
+
+
+def test_argument_checks_without_a_gpu():
+    lib = _lib.load()
+    rc = lib.tc_gemm(1, 0, 16, 64, 16, 16, None, 16, 100, 4, 100, 64, 0.0, None, None, 0, 0, None)
+    assert rc == -1 and b"multiple of 128" in lib.tc_last_error()
+    rc = lib.tc_attn_fwd(1, 16, 384, None, 16, 1, 8, 2, 32, None)
+    assert rc == -1 and b"head_dim" in lib.tc_last_error()
+    rc = lib.tc_gemm(7, 0, 16, 64, 16, 16, None, 16, 128, 4, 128, 64, 0.0, None, None, 0, 0, None)
+    assert rc == -1

@@ -1,0 +1,257 @@
+"""Per-kernel parity through the C ABI against plain fp32 torch on the CPU.
+
+Tolerances: the f32 kernels must agree with an fp64-accumulated reference to a few f32
+ulps of the accumulated magnitude; the bf16 kernels are compared against the same fp32
+arithmetic applied to the bf16-rounded inputs (so the only differences are accumulation
+order and the bf16 rounding of the output)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import transcodon_ref as O
+from transcodon_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ---------------------------------------------------------------- GEMM
+def test_gemm_bf16_fragment_layout_exact():
+    """A = shifted identity pattern with small integers, asymmetric W: exact in bf16, so
+    any row/column swap or k-slot permutation error shows up as an integer mismatch."""
+    M, N, K = 256, 256, 128
+    a = torch.zeros(M, K)
+    for i in range(M):
+        a[i, (3 * i + 1) % K] = 1 + (i % 3)
+        a[i, (7 * i + 5) % K] += 2
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 13 - 6
+    w[:, 0] += torch.arange(N) % 5
+    bias = torch.arange(N, dtype=torch.float32) % 7
+    out = ops.gemm(a.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16), bias.to(DEV))
+    ref = a @ w.t() + bias
+    assert torch.equal(out.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(131, 128, 128), (1000, 768, 768), (257, 384, 3072), (64, 2304, 768)])
+def test_gemm_bias_and_gelu(dtype, M, N, K):
+    a, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.05), _rand(N, seed=3)
+    if dtype == torch.bfloat16:
+        a, w = _bf(a), _bf(w)
+    ref = (a.double() @ w.double().t() + b.double())
+    for epi, f in ((_lib.EPI_BIAS, lambda x: x), (_lib.EPI_BIAS_GELU, lambda x: O.gelu(x))):
+        out = ops.gemm(a.to(DEV, dtype), w.to(DEV, dtype), b.to(DEV), epi).float().cpu()
+        want = f(ref).float()
+        if dtype == torch.bfloat16:
+            np.testing.assert_allclose(out.numpy(), want.numpy(), rtol=1e-2, atol=2e-2)
+        else:
+            np.testing.assert_allclose(out.numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_residual_in_place(dtype):
+    M, N, K = 300, 256, 512
+    a, w, b, r = _rand(M, K, seed=4), _rand(N, K, seed=5, scale=0.05), _rand(N, seed=6), _rand(M, N, seed=7)
+    if dtype == torch.bfloat16:
+        a, w = _bf(a), _bf(w)
+    ref = (r.double() + (a.double() @ w.double().t() + b.double())).float()
+    res = r.to(DEV).clone()
+    out = ops.gemm(a.to(DEV, dtype), w.to(DEV, dtype), b.to(DEV), _lib.EPI_BIAS_RESIDUAL, residual=res, out=res)
+    assert out.data_ptr() == res.data_ptr() and out.dtype == torch.float32
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=3e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_qkv_rope(dtype):
+    B, T, H = 3, 50, 2
+    E, D = H * 64, 64
+    M = B * T
+    x, w, b = _rand(M, E, seed=8), _rand(3 * E, E, seed=9, scale=0.1), _rand(3 * E, seed=10, scale=0.1)
+    if dtype == torch.bfloat16:
+        x, w = _bf(x), _bf(w)
+    freqs = O.rope_freqs(D)
+    ang = torch.arange(T, dtype=torch.float32)[:, None] * freqs[None, :]
+    out = ops.gemm(x.to(DEV, dtype), w.to(DEV, dtype), b.to(DEV), _lib.EPI_QKV_ROPE, q_scale=0.125,
+                   rope_cos=ang.cos().contiguous().to(DEV), rope_sin=ang.sin().contiguous().to(DEV),
+                   T=T, head_dim=D).float().cpu()
+    y = x @ w.t() + b
+    q, k, v = y[:, :E] * 0.125, y[:, E:2 * E], y[:, 2 * E:]
+
+    def rot(t):  # [M,E] -> rope per head with position = row % T
+        t = t.view(B, T, H, D).permute(0, 2, 1, 3)
+        return O.rope_rotate(t, freqs).permute(0, 2, 1, 3).reshape(M, E)
+
+    ref = torch.cat([rot(q), rot(k), v], dim=1)
+    tol = dict(rtol=1e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), **tol)
+
+
+def test_gemm_rejects_bad_shapes():
+    a = torch.zeros(8, 64, device=DEV, dtype=torch.bfloat16)
+    w = torch.zeros(100, 64, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(_lib.HipLibraryError):
+        ops.gemm(a, w, torch.zeros(100, device=DEV))
+
+
+# ---------------------------------------------------------------- row kernels
+def test_embed_pad_zero_and_bad_index():
+    V, S, E = 10, 16, 128
+    tokt, spt = _rand(V, E, seed=11), _rand(S, E, seed=12)
+    tok = torch.tensor([[0, 5, 6, 9, 2, 1, 1], [0, 8, 7, 4, 5, 6, 2]])
+    sp = torch.tensor([3, 15])
+    x, pad, bad = ops.embed(tok.to(DEV), sp.to(DEV), tokt.to(DEV), spt.to(DEV))
+    ref = (tokt[tok] + spt[sp][:, None, :]) * (tok != 1)[..., None]
+    assert torch.equal(x.cpu().view(2, 7, E), ref)
+    assert pad.cpu().view(2, 7).tolist() == (tok == 1).int().tolist() and int(bad.item()) == 0
+    tok[0, 2] = 10
+    x, _, bad = ops.embed(tok.to(DEV), sp.to(DEV), tokt.to(DEV), spt.to(DEV))
+    assert int(bad.item()) == 1 and float(x.view(2, 7, E)[0, 2].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("E", [128, 768, 1024])
+def test_layernorm(E):
+    M = 37
+    x, g, b = _rand(M, E, seed=13, scale=3.0) + 0.5, _rand(E, seed=14), _rand(E, seed=15)
+    ref = torch.nn.functional.layer_norm(x, (E,), g, b, 1e-5)
+    y = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, torch.float32).cpu()
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    yb = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, torch.bfloat16).float().cpu()
+    np.testing.assert_allclose(yb.numpy(), ref.numpy(), rtol=8e-3, atol=8e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_head_logits(dtype):
+    M, E, V = 45, 768, 10
+    gbuf = _rand(M, 2 * E, seed=16)
+    if dtype == torch.bfloat16:
+        gbuf = _bf(gbuf)
+    gam, bet, W, bias = _rand(E, seed=17), _rand(E, seed=18), _rand(V, E, seed=19, scale=0.05), _rand(V, seed=20)
+    for col0 in (0, E):
+        ref = torch.nn.functional.layer_norm(gbuf[:, col0:col0 + E], (E,), gam, bet, 1e-5) @ W.t() + bias
+        out = ops.head_logits(gbuf.to(DEV, dtype), col0, E, gam.to(DEV), bet.to(DEV), W.to(DEV), bias.to(DEV)).cpu()
+        np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_key_mask_words():
+    B, T = 3, 150
+    pad = torch.zeros(B, T, dtype=torch.uint8)
+    pad[0, 100:] = 1
+    pad[1, 64:] = 1
+    pad[2, 7] = 1
+    words = ops.key_mask_words(pad.to(DEV).view(-1), B, T).cpu().numpy().view(np.uint64)
+    for b in range(B):
+        for w in range(3):
+            want = 0
+            for j in range(64):
+                k = 64 * w + j
+                if k < T and pad[b, k] == 0:
+                    want |= 1 << j
+            assert int(words[b, w]) == want
+
+
+# ---------------------------------------------------------------- attention
+def _attn_ref(qkv, B, T, H, pad):
+    E = H * 64
+    q, k, v = (qkv[:, i * E:(i + 1) * E].view(B, T, H, 64).permute(0, 2, 1, 3).double() for i in range(3))
+    s = q @ k.transpose(-1, -2)
+    if pad is not None:
+        s = s.masked_fill(pad.bool()[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * T, E).float(), s.float()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,T,H,lens", [(2, 131, 2, None), (3, 256, 3, [256, 130, 1]), (2, 70, 1, [70, 64]),
+                                        (1, 515, 2, None)])
+def test_attention_forward(dtype, B, T, H, lens):
+    E = H * 64
+    qkv = _rand(B * T, 3 * E, seed=21)
+    qkv[:, :E] *= 0.25
+    if dtype == torch.bfloat16:
+        qkv = _bf(qkv)
+    pad = None
+    if lens is not None:
+        pad = torch.zeros(B, T, dtype=torch.uint8)
+        for b, L in enumerate(lens):
+            pad[b, L:] = 1
+    ref, sref = _attn_ref(qkv, B, T, H, pad)
+    words = ops.key_mask_words(pad.to(DEV).view(-1), B, T) if pad is not None else None
+    out = ops.attention(qkv.to(DEV, dtype), B, T, H, words).float().cpu()
+    keep = torch.ones(B * T, dtype=torch.bool) if pad is None else (pad.view(-1) == 0)
+    tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out[keep].numpy(), ref[keep].numpy(), **tol)
+    sc = ops.attention_scores(qkv.to(DEV, dtype), B, T, H, pad.to(DEV).view(-1) if pad is not None else None).cpu()
+    finite = torch.isfinite(sref)
+    assert torch.equal(torch.isfinite(sc), finite)
+    np.testing.assert_allclose(sc[finite].numpy(), sref[finite].numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_attention_online_softmax_rescale():
+    """A key far above the others late in the sequence forces the running-max rescale."""
+    B, T, H = 1, 192, 1
+    qkv = _bf(_rand(T, 192, seed=22))
+    qkv[:, :64] *= 0.1
+    qkv[150, 64:128] = _bf(qkv[5, :64] * 40.0)      # key 150 aligned with query 5
+    ref, _ = _attn_ref(qkv, B, T, H, None)
+    out = ops.attention(qkv.to(DEV, torch.bfloat16), B, T, H).float().cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+
+
+# ---------------------------------------------------------------- decode and loss
+def test_decode_known_answers(golden_dir):
+    kats = json.load(open(os.path.join(golden_dir, "decode_kat.json")))
+    for k in kats:
+        logits = torch.tensor(k["logits"], dtype=torch.float32)
+        m = len(k["aa"])
+        aa = torch.tensor(list(ops.encode_amino_acids(k["aa"])), dtype=torch.uint8, device=DEV)
+        bases = ops.codon_decode(logits.to(DEV), aa, torch.tensor([0, m], dtype=torch.int32, device=DEV),
+                                 torch.tensor([0], dtype=torch.int32, device=DEV))
+        assert bytes(bases.cpu().numpy()).decode() == k["rna"], k["name"]
+
+
+def test_decode_ragged_batch_against_oracle():
+    rng = np.random.default_rng(3)
+    letters = list(O.AA2CODONS.keys())
+    seqs = ["".join(rng.choice(letters, size=n)) for n in (1, 17, 300, 2049)]
+    width = 3 * 2049 + 9
+    logits = torch.from_numpy(rng.standard_normal((len(seqs), width, 10)).astype(np.float32) * 3)
+    starts = [0, 5, 9, 1]
+    offs, row0 = [0], []
+    for r, s in enumerate(seqs):
+        offs.append(offs[-1] + len(s))
+        row0.append(r * width + starts[r])
+    aa = torch.tensor(list(b"".join(ops.encode_amino_acids(s) for s in seqs)), dtype=torch.uint8, device=DEV)
+    bases = ops.codon_decode(logits.view(-1, 10).to(DEV), aa, torch.tensor(offs, dtype=torch.int32, device=DEV),
+                             torch.tensor(row0, dtype=torch.int32, device=DEV))
+    flat = bytes(bases.cpu().numpy()).decode()
+    for r, s in enumerate(seqs):
+        want = O.decode(logits[r, starts[r]:starts[r] + 3 * len(s)], s)
+        assert flat[3 * offs[r]:3 * offs[r + 1]] == want
+
+
+def test_ce_loss_matches_torch():
+    M, V = 1000, 10
+    logits = _rand(M, V, seed=23, scale=2.0)
+    labels = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(1))
+    labels[torch.rand(M, generator=torch.Generator().manual_seed(2)) < 0.7] = -100
+    lg = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lg, labels, ignore_index=-100)
+    ref.backward()
+    n = int((labels != -100).sum())
+    loss, cnt, dl = ops.ce_loss(logits.to(DEV), labels.to(DEV), want_grad=True, grad_scale=1.0 / n)
+    assert int(cnt.item()) == n
+    np.testing.assert_allclose(float(loss.item()) / n, float(ref), rtol=1e-5)
+    np.testing.assert_allclose(dl.cpu().numpy(), lg.grad.numpy(), rtol=1e-4, atol=1e-7)

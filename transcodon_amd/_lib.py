@@ -1,0 +1,96 @@
+"""ctypes binding of libtranscodon_hip.so (declarations: include/transcodon_hip.h).
+
+The library is built in-tree (``make -C transcodon_amd/csrc``).  There is no CPU
+fallback: if the shared object is missing or a call fails, an exception is raised.
+"""
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtranscodon_hip.so")
+
+TC_F32, TC_BF16 = 0, 1
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_QKV_ROPE = 0, 1, 2, 3
+PROF_GEMM, PROF_ATTN, PROF_LAYERNORM, PROF_EMBED, PROF_HEAD, PROF_DECODE = range(6)
+
+vp = C.c_void_p
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [(n, vp) for n in (
+        "ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_g", "ln2_b",
+        "w_fc1", "b_fc1", "w_fc2", "b_fc2", "rope_cos", "rope_sin")]
+
+
+class EncoderDesc(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ("dtype", "num_layers", "E", "F", "H", "vocab", "n_species",
+                                  "n_struct", "pad_idx", "rope_table_len")]
+        + [("ln_eps", C.c_float)]
+        + [(n, vp) for n in ("tok_table", "species_table")]
+        + [("layers", C.POINTER(LayerWeights))]
+        + [(n, vp) for n in ("lnf_g", "lnf_b", "w_heads", "b_heads", "lm_ln_g", "lm_ln_b",
+                             "lm_bias", "st_ln_g", "st_ln_b", "st_w", "st_bias")]
+    )
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_SIGNATURES = {
+    "tc_version": (C.c_int, []),
+    "tc_last_error": (C.c_char_p, []),
+    "tc_embed_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
+    "tc_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
+    "tc_gemm": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
+                          C.c_int, C.c_int, C.c_float, vp, vp, C.c_int, C.c_int, vp]),
+    "tc_key_mask_words": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    "tc_attn_fwd": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "tc_attn_scores": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "tc_head_logits_fwd": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp,
+                                     C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "tc_codon_decode": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "tc_ce_loss_fwd_bwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp]),
+    "tc_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc), C.c_int, C.c_int]),
+    "tc_encoder_forward": (C.c_int, [C.POINTER(EncoderDesc), vp, vp, C.c_int, C.c_int, vp, vp, vp,
+                                     C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), vp, vp,
+                                     C.c_size_t, vp]),
+    "tc_prof_enable": (C.c_int, [C.c_int]),
+    "tc_prof_reset": (C.c_int, []),
+    "tc_prof_collect": (C.c_int, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+_lib = None
+
+
+def load():
+    """Load the shared library once; raises HipLibraryError when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} not found: build it with `make -C transcodon_amd/csrc` "
+                "(there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().tc_last_error().decode(errors="replace")
+        raise HipLibraryError(f"{what or 'libtranscodon_hip'} failed ({rc}): {msg}")
+
+
+def prof_collect(kind):
+    n, ms, work = C.c_int64(0), C.c_double(0), C.c_double(0)
+    check(load().tc_prof_collect(kind, C.byref(n), C.byref(ms), C.byref(work)), "tc_prof_collect")
+    return n.value, ms.value, work.value

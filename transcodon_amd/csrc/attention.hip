@@ -1,0 +1,407 @@
+// Fused multi-head self-attention forward for head_dim 64 (gfx950).
+//
+// bf16 kernel: a 256-thread workgroup (4 waves) owns 128 query rows of one (sequence,
+// head); each wave owns 32 of them.  K/V tiles of 64 keys are staged global -> LDS with
+// direct loads, double buffered.  Per tile and wave:
+//   S^T = K . Q^T   (mfma_f32_32x32x16_bf16, A = K rows from LDS, B = Q kept in registers)
+// leaves the query on the lane and 32 keys in registers, so the online softmax is
+// lane-local plus one exchange with lane ^ 32;
+//   O^T += V^T . P^T  takes the exponentiated accumulators directly as the B operand and
+// reads V^T fragments with the transposing LDS read (ds_read_b64_tr_b16) from the
+// row-major V tile.  The per-query rescale is then a per-lane scalar.
+// Padded keys get -inf through 64-bit validity words (one per sequence and key tile).
+//
+// f32 kernel (exactness path): one 64-lane wave per 64 queries, one query per lane,
+// plain fmaf dot products over keys broadcast from LDS.
+#include "common.h"
+
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+struct AttnParams {
+    const char *qkv;
+    const uint64_t *words;
+    char *out;
+    long ldq_bytes, ldo_bytes;
+    int B, T, H, E;
+    int nw;       // validity words per sequence = ceil(T/64)
+    int nqb;      // query blocks per (b,h)
+};
+
+// ------------------------------------------------------------------------------------------
+// bf16
+// ------------------------------------------------------------------------------------------
+constexpr int KV_TILE_BYTES = 64 * 128;            // 64 keys x 64 bf16
+constexpr int KV_STAGE_BYTES = 2 * KV_TILE_BYTES;  // K + V
+constexpr int OST_LD = 144;                        // bytes per staged output row (128 + pad)
+constexpr int OST_WAVE_BYTES = 32 * OST_LD;
+constexpr int ATTN_LDS_BYTES = 2 * KV_STAGE_BYTES + 4 * OST_WAVE_BYTES;
+
+__device__ __forceinline__ int swz_k(int row) { return (row >> 1) & 7; }          // row reads
+__device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }   // transposed reads
+
+__device__ __forceinline__ uint64_t key_word(const AttnParams &p, int b, int kt) {
+    if (p.words) return p.words[(long)b * p.nw + kt];
+    const int rem = p.T - kt * 64;
+    return rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+}
+
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int id = tc_xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = id % p.nqb;
+    const int bh = id / p.nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    const int ql = lane & 31, h2 = lane >> 5;
+    const int q0 = qb * 128 + wid * 32;
+    const long row_base = (long)b * p.T;
+
+    // number of key tiles up to the last one holding a valid key
+    int nkt = p.nw;
+    while (nkt > 0 && key_word(p, b, nkt - 1) == 0ull) --nkt;
+
+    // ---- Q fragments: B operand, lane (q, h2) holds Q[q][16 ks + 8 h2 .. +7] ----
+    bf16x8 qf[4];
+    {
+        int qr = q0 + ql;
+        qr = qr < p.T ? qr : p.T - 1;
+        const char *src = p.qkv + (row_base + qr) * p.ldq_bytes + (long)h * 128 + h2 * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(src + ks * 32);
+    }
+
+    // ---- staging: per tile and wave 2 pieces of K and 2 of V (8 rows x 128 B each) ----
+    const int srow = lane >> 3;
+    long k_src[2], v_src[2];      // byte offsets without the key-tile term
+    int s_row[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wid * 2 + i) * 8 + srow;
+        s_row[i] = r;
+        k_src[i] = (long)(p.E + h * 64) * 2 + (((lane & 7) ^ swz_k(r)) << 4);
+        v_src[i] = (long)(2 * p.E + h * 64) * 2 + (((lane & 7) ^ swz_v(r)) << 4);
+    }
+    auto stage = [&](int buf, int kt) {
+        char *kb = smem + buf * KV_STAGE_BYTES + wid * 2 * 1024;
+        char *vb = kb + KV_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int key = kt * 64 + s_row[i];
+            key = key < p.T ? key : p.T - 1;
+            const char *rowp = p.qkv + (row_base + key) * p.ldq_bytes;
+            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(rowp + k_src[i]), TC_LDS_PTR(kb + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(rowp + v_src[i]), TC_LDS_PTR(vb + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- LDS read offsets ----
+    // K rows: lane reads row kb*32 + ql, chunk 2 ks + h2
+    int k_off[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int r = kb * 32 + ql;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) k_off[kb][ks] = r * 128 + (((2 * ks + h2) ^ swz_k(r)) << 4);
+    }
+    // V transposed reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a
+    // 4-key x 16-column block and receives column (lane & 15) of the 4 keys.
+    const int tq = (lane & 15) >> 2, tp = lane & 3, thalf = (lane >> 4) & 1;
+    auto v_off = [&](int db, int key_row) {      // key_row = first key of the block + tq
+        const int c = 4 * db + 2 * thalf + (tp >> 1);
+        return KV_TILE_BYTES + key_row * 128 + ((c ^ swz_v(key_row)) << 4) + 8 * (tp & 1);
+    };
+
+    f32x16 acc_o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    if (nkt > 0) stage(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+        const char *sb = smem + (kt & 1) * KV_STAGE_BYTES;
+
+        // S^T[key][query]
+        f32x16 acc_s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_s[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(sb + k_off[kb][ks]);
+                acc_s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc_s[kb], 0, 0, 0);
+            }
+        }
+
+        // mask + online softmax (base 2)
+        const uint64_t word = key_word(p, b, kt);
+        const uint64_t wsh = word >> (4 * h2);
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const uint32_t wk = (uint32_t)(wsh >> (32 * kb));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s = acc_s[kb][r] * kLog2e;
+                if (word != ~0ull) {
+                    const int bit = (r & 3) + 8 * (r >> 2);
+                    s = ((wk >> bit) & 1u) ? s : -INFINITY;
+                }
+                acc_s[kb][r] = s;
+                tmax = fmaxf(tmax, s);
+            }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        float lsum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(acc_s[kb][r] - m_use);
+                acc_s[kb][r] = e;
+                lsum += e;
+            }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+
+        // O^T[d][query] += V^T . P^T ; P fragment of k-step (kb, s) = registers 8s..8s+7
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (__bf16)acc_s[kb][8 * s + j];
+                const int key0 = kb * 32 + 16 * s + 4 * h2 + tq;   // + 8 for elements 4..7
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4 *)(sb + v_off(db, key0)));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4 *)(sb + v_off(db, key0 + 8)));
+                    bf16x8 vf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                    acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc_o[db], 0, 0, 0);
+                }
+            }
+    }
+
+    // ---- epilogue: normalise, stage through the wave's LDS rows, store 16 B per lane ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    char *ost = smem + 2 * KV_STAGE_BYTES + wid * OST_WAVE_BYTES;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2 w;
+            w[0] = tc_pack_bf16(acc_o[db][4 * g] * inv, acc_o[db][4 * g + 1] * inv);
+            w[1] = tc_pack_bf16(acc_o[db][4 * g + 2] * inv, acc_o[db][4 * g + 3] * inv);
+            const int d = 32 * db + 8 * g + 4 * h2;
+            *reinterpret_cast<u32x2 *>(ost + ql * OST_LD + d * 2) = w;
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3), c = lane & 7;
+        const u32x4 w = *reinterpret_cast<const u32x4 *>(ost + r * OST_LD + c * 16);
+        const int q = q0 + r;
+        if (q < p.T)
+            *reinterpret_cast<u32x4 *>(p.out + (row_base + q) * p.ldo_bytes + (long)h * 128 + c * 16) = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// f32: one query per lane
+// ------------------------------------------------------------------------------------------
+constexpr int F32_KT = 32;   // keys per LDS tile
+
+__global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float ks[F32_KT][64];
+    __shared__ __attribute__((aligned(16))) float vs[F32_KT][64];
+    const int lane = threadIdx.x;
+    const int qb = blockIdx.x % p.nqb;
+    const int bh = blockIdx.x / p.nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    const long row_base = (long)b * p.T;
+    int qi = qb * 64 + lane;
+    const bool q_ok = qi < p.T;
+    qi = q_ok ? qi : p.T - 1;
+
+    float q[64], o[64];
+    {
+        const float *src = reinterpret_cast<const float *>(p.qkv + (row_base + qi) * p.ldq_bytes) + h * 64;
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(src + d);
+            q[d] = v[0]; q[d + 1] = v[1]; q[d + 2] = v[2]; q[d + 3] = v[3];
+        }
+#pragma unroll
+        for (int d = 0; d < 64; ++d) o[d] = 0.f;
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = 0; k0 < p.T; k0 += F32_KT) {
+        const uint64_t word = key_word(p, b, k0 >> 6);
+        const uint32_t bits = (uint32_t)(word >> (k0 & 63));
+        if (bits == 0u) continue;                                   // uniform: no valid key here
+        __syncthreads();
+        // 32 keys x 64 floats for K and V = 2 x 512 float4, 8 + 8 per lane
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = i * 64 + lane;        // float4 index in the tile
+            const int r = idx >> 4, c4 = idx & 15;
+            int key = k0 + r;
+            key = key < p.T ? key : p.T - 1;
+            const float *rowp = reinterpret_cast<const float *>(p.qkv + (row_base + key) * p.ldq_bytes);
+            *reinterpret_cast<f32x4 *>(&ks[r][c4 * 4]) =
+                *reinterpret_cast<const f32x4 *>(rowp + p.E + h * 64 + c4 * 4);
+            *reinterpret_cast<f32x4 *>(&vs[r][c4 * 4]) =
+                *reinterpret_cast<const f32x4 *>(rowp + 2 * p.E + h * 64 + c4 * 4);
+        }
+        __syncthreads();
+        float s[F32_KT];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < F32_KT; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) acc = fmaf(q[d], ks[j][d], acc);
+            s[j] = ((bits >> j) & 1u) ? acc : -INFINITY;
+            tmax = fmaxf(tmax, s[j]);
+        }
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = expf(m_run - m_new);   // m_new is finite: the tile has a valid key
+        float lsum = 0.f;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) o[d] *= alpha;
+#pragma unroll
+        for (int j = 0; j < F32_KT; ++j) {
+            const float e = expf(s[j] - m_new);
+            lsum += e;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) o[d] = fmaf(e, vs[j][d], o[d]);
+        }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+    }
+    if (q_ok) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        float *dst = reinterpret_cast<float *>(p.out + (row_base + qi) * p.ldo_bytes) + h * 64;
+#pragma unroll
+        for (int d = 0; d < 64; d += 4)
+            *reinterpret_cast<f32x4 *>(dst + d) = f32x4{o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pre-softmax scores (slow path for callers that ask for attention maps)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void scores_kernel(const T *__restrict__ qkv, long ldq,
+                                                     const uint8_t *__restrict__ pad,
+                                                     float *__restrict__ scores, int Tn, int H,
+                                                     int E) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    const int bh = blockIdx.z;
+    const int h = bh % H, b = bh / H;
+    if (j >= Tn) return;
+    const T *q = qkv + ((long)b * Tn + i) * ldq + h * 64;
+    const T *k = qkv + ((long)b * Tn + j) * ldq + E + h * 64;
+    float acc = 0.f;
+    for (int d = 0; d < 64; ++d) {
+        float a, c;
+        if constexpr (sizeof(T) == 2) {
+            a = __builtin_bit_cast(float, (uint32_t)q[d] << 16);
+            c = __builtin_bit_cast(float, (uint32_t)k[d] << 16);
+        } else {
+            a = q[d];
+            c = k[d];
+        }
+        acc = fmaf(a, c, acc);
+    }
+    if (pad && pad[(long)b * Tn + j]) acc = -INFINITY;
+    scores[(((long)b * H + h) * Tn + i) * Tn + j] = acc;
+}
+
+}  // namespace
+
+extern "C" int tc_attn_fwd(int dtype, const void *qkv, int ldq, const uint64_t *key_words,
+                           void *out, int B, int T, int H, int D, void *stream) {
+    TC_REQUIRE(dtype == TC_BF16 || dtype == TC_F32, "tc_attn_fwd: bad dtype %d", dtype);
+    TC_REQUIRE(qkv && out, "tc_attn_fwd: null operand");
+    TC_REQUIRE(D == 64, "tc_attn_fwd: head_dim %d unsupported (only 64)", D);
+    TC_REQUIRE(B > 0 && T > 0 && H > 0, "tc_attn_fwd: bad shape B=%d T=%d H=%d", B, T, H);
+    const int E = H * D;
+    const int esz = dtype == TC_BF16 ? 2 : 4;
+    TC_REQUIRE(ldq >= 3 * E && (ldq * esz) % 16 == 0, "tc_attn_fwd: ldq=%d too small or misaligned", ldq);
+    TC_REQUIRE(tc_aligned16(qkv) && tc_aligned16(out), "tc_attn_fwd: operands must be 16-byte aligned");
+    AttnParams p{};
+    p.qkv = static_cast<const char *>(qkv);
+    p.words = key_words;
+    p.out = static_cast<char *>(out);
+    p.ldq_bytes = (long)ldq * esz;
+    p.ldo_bytes = (long)E * esz;
+    p.B = B; p.T = T; p.H = H; p.E = E;
+    p.nw = (T + 63) / 64;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TcProfScope prof(TC_PROF_ATTN, s, 4.0 * (double)B * H * (double)T * (double)T * D);
+    if (dtype == TC_BF16) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bf16_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS_BYTES);
+            if (e != hipSuccess) {
+                tc_set_error("tc_attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                return TC_ELAUNCH;
+            }
+            attr_set = true;
+        }
+        p.nqb = (T + 127) / 128;
+        const long grid = (long)p.nqb * H * B;
+        TC_REQUIRE(grid < (1L << 31), "tc_attn_fwd: grid too large");
+        hipLaunchKernelGGL(attn_bf16_kernel, dim3((unsigned)grid), dim3(256), ATTN_LDS_BYTES, s, p);
+    } else {
+        p.nqb = (T + 63) / 64;
+        const long grid = (long)p.nqb * H * B;
+        TC_REQUIRE(grid < (1L << 31), "tc_attn_fwd: grid too large");
+        hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)grid), dim3(64), 0, s, p);
+    }
+    TC_CHECK_LAUNCH("tc_attn_fwd");
+    return TC_OK;
+}
+
+extern "C" int tc_attn_scores(int dtype, const void *qkv, int ldq, const uint8_t *pad_flags,
+                              float *scores, int B, int T, int H, int D, void *stream) {
+    TC_REQUIRE(dtype == TC_BF16 || dtype == TC_F32, "tc_attn_scores: bad dtype %d", dtype);
+    TC_REQUIRE(qkv && scores && D == 64 && B > 0 && T > 0 && H > 0, "tc_attn_scores: bad arguments");
+    TC_REQUIRE(T <= 65535 && (long)B * H <= 65535, "tc_attn_scores: shape too large for the slow path");
+    const int E = H * D;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((T + 255) / 256, T, B * H), block(256);
+    if (dtype == TC_BF16)
+        hipLaunchKernelGGL(scores_kernel<uint16_t>, grid, block, 0, s, static_cast<const uint16_t *>(qkv),
+                           (long)ldq, pad_flags, scores, T, H, E);
+    else
+        hipLaunchKernelGGL(scores_kernel<float>, grid, block, 0, s, static_cast<const float *>(qkv),
+                           (long)ldq, pad_flags, scores, T, H, E);
+    TC_CHECK_LAUNCH("tc_attn_scores");
+    return TC_OK;
+}

@@ -1,0 +1,87 @@
+// Internal helpers shared by the gfx950 kernels of libtranscodon_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/transcodon_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define TC_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
+#define TC_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+// ---- error reporting (host) ---------------------------------------------------------
+void tc_set_error(const char *fmt, ...);
+
+#define TC_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            tc_set_error(__VA_ARGS__);        \
+            return TC_EINVAL;                 \
+        }                                     \
+    } while (0)
+
+#define TC_CHECK_LAUNCH(what)                                                   \
+    do {                                                                        \
+        hipError_t e__ = hipGetLastError();                                     \
+        if (e__ != hipSuccess) {                                                \
+            tc_set_error("%s: %s", what, hipGetErrorString(e__));               \
+            return TC_ELAUNCH;                                                  \
+        }                                                                       \
+    } while (0)
+
+static inline bool tc_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---- per-kernel-family event timing ---------------------------------------------------
+// A scope object brackets the launches issued between its construction and destruction
+// with two events on `stream` when profiling is enabled; otherwise it does nothing.
+struct TcProfScope {
+    int kind;
+    hipStream_t stream;
+    void *slot;
+    TcProfScope(int kind, hipStream_t stream, double work);
+    ~TcProfScope();
+};
+
+// ---- device helpers ---------------------------------------------------------------
+__device__ __forceinline__ float tc_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float tc_wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// exact erf GELU, x * 0.5 * (1 + erf(x / sqrt(2)))
+__device__ __forceinline__ float tc_gelu(float x) {
+    return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ uint32_t tc_pack_bf16(float lo, float hi) {
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float tc_bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float tc_bf16_hi(uint32_t w) {
+    return __builtin_bit_cast(float, w & 0xffff0000u);
+}
+
+// XCD-aware remap of a linear workgroup id: workgroups that the dispatcher deals to the
+// same XCD (id % 8 equal) get a contiguous range of logical ids, so neighbouring tiles
+// share that XCD's L2.  Bijective for any grid size.
+__device__ __forceinline__ int tc_xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = id & 7, k = id >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}

@@ -1,0 +1,151 @@
+// Whole-encoder forward: strings the kernels together on one stream, no host sync.
+#include "common.h"
+
+namespace {
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Workspace {
+    float *x;          // residual stream f32 [M,E]
+    void *h;           // LayerNorm output / attention output [M,E] (dtype)
+    void *qkv;         // [M,3E] (dtype)
+    void *mid;         // [M,max(F,2E)] (dtype)
+    uint8_t *pad;      // [M]
+    uint64_t *words;   // [B, ceil(T/64)]
+    size_t total;
+};
+
+Workspace carve(const tc_encoder_desc *d, int B, int T, char *base) {
+    const size_t M = (size_t)B * T;
+    const size_t esz = d->dtype == TC_BF16 ? 2 : 4;
+    const size_t wide = (size_t)(d->F > 2 * d->E ? d->F : 2 * d->E);
+    Workspace w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *p = base ? base + off : nullptr;
+        off += align_up(bytes);
+        return p;
+    };
+    w.x = reinterpret_cast<float *>(take(M * d->E * 4));
+    w.h = take(M * d->E * esz);
+    w.qkv = take(M * 3 * d->E * esz);
+    w.mid = take(M * wide * esz);
+    w.pad = reinterpret_cast<uint8_t *>(take(M));
+    w.words = reinterpret_cast<uint64_t *>(take((size_t)B * ((T + 63) / 64) * 8));
+    w.total = off;
+    return w;
+}
+
+int check_desc(const tc_encoder_desc *d) {
+    TC_REQUIRE(d != nullptr, "encoder: null descriptor");
+    TC_REQUIRE(d->dtype == TC_BF16 || d->dtype == TC_F32, "encoder: bad dtype %d", d->dtype);
+    TC_REQUIRE(d->num_layers > 0 && d->layers, "encoder: no layers");
+    TC_REQUIRE(d->E > 0 && d->H > 0 && d->E == d->H * 64, "encoder: E=%d H=%d needs head_dim 64", d->E, d->H);
+    TC_REQUIRE(d->E % 128 == 0 && d->F % 128 == 0, "encoder: E=%d and F=%d must be multiples of 128", d->E, d->F);
+    TC_REQUIRE(d->vocab > 0 && d->vocab <= 16 && d->n_struct >= 0 && d->n_struct <= 16, "encoder: head widths out of range");
+    TC_REQUIRE(d->tok_table && d->species_table && d->lnf_g && d->lnf_b && d->w_heads && d->b_heads &&
+                   d->lm_ln_g && d->lm_ln_b && d->lm_bias,
+               "encoder: null weight pointer");
+    return TC_OK;
+}
+
+}  // namespace
+
+extern "C" size_t tc_workspace_bytes(const tc_encoder_desc *desc, int B, int T) {
+    if (!desc || B <= 0 || T <= 0) return 0;
+    return carve(desc, B, T, nullptr).total;
+}
+
+#define TC_TRY(expr)                 \
+    do {                             \
+        int rc__ = (expr);           \
+        if (rc__ != TC_OK) return rc__; \
+    } while (0)
+
+extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *tokens,
+                                  const int32_t *species, int B, int T, float *logits,
+                                  float *struct_logits, float *rep_last, int n_rep,
+                                  const int32_t *rep_layer, float *const *rep_out, int32_t *status,
+                                  void *workspace, size_t workspace_bytes, void *stream) {
+    TC_TRY(check_desc(d));
+    TC_REQUIRE(tokens && species && logits && workspace, "tc_encoder_forward: null operand");
+    TC_REQUIRE(B > 0 && T > 0 && (long)B * T < (1L << 31), "tc_encoder_forward: bad batch B=%d T=%d", B, T);
+    TC_REQUIRE(T <= d->rope_table_len, "tc_encoder_forward: T=%d exceeds the rope table (%d rows)", T, d->rope_table_len);
+    TC_REQUIRE(!struct_logits || (d->st_ln_g && d->st_ln_b && d->st_w && d->st_bias && d->n_struct > 0),
+               "tc_encoder_forward: structure head requested without its weights");
+    TC_REQUIRE(tc_aligned16(workspace), "tc_encoder_forward: workspace must be 16-byte aligned");
+    Workspace w = carve(d, B, T, static_cast<char *>(workspace));
+    if (w.total > workspace_bytes) {
+        tc_set_error("tc_encoder_forward: workspace %zu bytes, need %zu", workspace_bytes, w.total);
+        return TC_ENOSPC;
+    }
+    for (int i = 0; i < n_rep; ++i)
+        TC_REQUIRE(rep_layer && rep_out && rep_layer[i] >= 0 && rep_layer[i] < d->num_layers && rep_out[i],
+                   "tc_encoder_forward: bad representation request %d", i);
+
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int M = B * T, E = d->E, F = d->F, dt = d->dtype;
+    const bool bf = dt == TC_BF16;
+    auto ln = [&](const float *g, const float *b, float *extra_f32) {
+        return tc_layernorm_fwd(w.x, g, b, bf ? extra_f32 : static_cast<float *>(w.h),
+                                bf ? w.h : nullptr, M, E, d->ln_eps, stream);
+    };
+    auto save_rep = [&](int layer) -> int {
+        for (int i = 0; i < n_rep; ++i)
+            if (rep_layer[i] == layer) {
+                hipError_t e = hipMemcpyAsync(rep_out[i], w.x, (size_t)M * E * 4, hipMemcpyDeviceToDevice, s);
+                if (e != hipSuccess) {
+                    tc_set_error("tc_encoder_forward: representation copy: %s", hipGetErrorString(e));
+                    return TC_ELAUNCH;
+                }
+            }
+        return TC_OK;
+    };
+
+    TC_TRY(tc_embed_fwd(tokens, species, d->tok_table, d->species_table, w.x, w.pad, status, B, T, E,
+                        d->vocab, d->n_species, d->pad_idx, stream));
+    TC_TRY(tc_key_mask_words(w.pad, w.words, B, T, stream));
+    TC_TRY(save_rep(0));
+
+    for (int l = 0; l < d->num_layers; ++l) {
+        const tc_layer_weights &lw = d->layers[l];
+        TC_REQUIRE(lw.ln1_g && lw.ln1_b && lw.w_qkv && lw.b_qkv && lw.w_o && lw.b_o && lw.ln2_g && lw.ln2_b &&
+                       lw.w_fc1 && lw.b_fc1 && lw.w_fc2 && lw.b_fc2 && lw.rope_cos && lw.rope_sin,
+                   "tc_encoder_forward: layer %d has a null weight pointer", l);
+        TC_TRY(ln(lw.ln1_g, lw.ln1_b, nullptr));
+        TC_TRY(tc_gemm(dt, TC_EPI_QKV_ROPE, w.h, E, lw.w_qkv, lw.b_qkv, nullptr, w.qkv, 3 * E, M, 3 * E, E,
+                       0.125f, lw.rope_cos, lw.rope_sin, T, 64, stream));
+        TC_TRY(tc_attn_fwd(dt, w.qkv, 3 * E, w.words, w.h, B, T, d->H, 64, stream));
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.h, E, lw.w_o, lw.b_o, w.x, w.x, E, M, E, E, 0.f, nullptr,
+                       nullptr, 0, 0, stream));
+        TC_TRY(ln(lw.ln2_g, lw.ln2_b, nullptr));
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_GELU, w.h, E, lw.w_fc1, lw.b_fc1, nullptr, w.mid, F, M, F, E, 0.f,
+                       nullptr, nullptr, 0, 0, stream));
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.mid, F, lw.w_fc2, lw.b_fc2, w.x, w.x, E, M, E, F, 0.f,
+                       nullptr, nullptr, 0, 0, stream));
+        if (l + 1 < d->num_layers) TC_TRY(save_rep(l + 1));
+    }
+
+    // final LayerNorm; the f32 copy doubles as representations[num_layers]
+    if (bf) {
+        TC_TRY(tc_layernorm_fwd(w.x, d->lnf_g, d->lnf_b, rep_last, w.h, M, E, d->ln_eps, stream));
+    } else {
+        TC_TRY(tc_layernorm_fwd(w.x, d->lnf_g, d->lnf_b, static_cast<float *>(w.h), nullptr, M, E, d->ln_eps, stream));
+        if (rep_last) {
+            hipError_t e = hipMemcpyAsync(rep_last, w.h, (size_t)M * E * 4, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) {
+                tc_set_error("tc_encoder_forward: representation copy: %s", hipGetErrorString(e));
+                return TC_ELAUNCH;
+            }
+        }
+    }
+    const int nheads = struct_logits ? 2 : 1;
+    TC_TRY(tc_gemm(dt, TC_EPI_BIAS_GELU, w.h, E, d->w_heads, d->b_heads, nullptr, w.mid, nheads * E, M,
+                   nheads * E, E, 0.f, nullptr, nullptr, 0, 0, stream));
+    TC_TRY(tc_head_logits_fwd(dt, w.mid, nheads * E, 0, d->lm_ln_g, d->lm_ln_b, d->tok_table, d->lm_bias,
+                              logits, M, E, d->vocab, d->ln_eps, stream));
+    if (struct_logits)
+        TC_TRY(tc_head_logits_fwd(dt, w.mid, nheads * E, E, d->st_ln_g, d->st_ln_b, d->st_w, d->st_bias,
+                                  struct_logits, M, E, d->n_struct, d->ln_eps, stream));
+    return TC_OK;
+}

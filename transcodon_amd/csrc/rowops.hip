@@ -1,0 +1,421 @@
+// HBM-bound row kernels: embedding gather, LayerNorm, output heads, codon decode, CE loss.
+// One 64-lane wave owns one row; lanes read 16 bytes at a time; reductions are
+// wave-wide shuffles, no LDS.
+#include "common.h"
+
+namespace {
+
+// ---- embedding ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const int32_t *__restrict__ tokens,
+                                                    const int32_t *__restrict__ species,
+                                                    const float *__restrict__ tok_table,
+                                                    const float *__restrict__ sp_table,
+                                                    float *__restrict__ x, uint8_t *pad_flags,
+                                                    int32_t *bad_index, int M, int T, int E,
+                                                    int vocab, int n_species, int pad_idx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int tok = tokens[row];
+    const int sp = species[row / T];
+    const bool bad = tok < 0 || tok >= vocab || sp < 0 || sp >= n_species;
+    const bool pad = tok == pad_idx;
+    if (lane == 0) {
+        if (pad_flags) pad_flags[row] = pad ? 1 : 0;
+        if (bad && bad_index) *bad_index = 1;
+    }
+    float *dst = x + (long)row * E;
+    if (pad || bad) {
+        for (int c = lane * 4; c < E; c += 256) *reinterpret_cast<f32x4 *>(dst + c) = f32x4{0, 0, 0, 0};
+        return;
+    }
+    const float *a = tok_table + (long)tok * E;
+    const float *b = sp_table + (long)sp * E;
+    for (int c = lane * 4; c < E; c += 256) {
+        const f32x4 va = *reinterpret_cast<const f32x4 *>(a + c);
+        const f32x4 vb = *reinterpret_cast<const f32x4 *>(b + c);
+        *reinterpret_cast<f32x4 *>(dst + c) = va + vb;
+    }
+}
+
+// ---- LayerNorm -----------------------------------------------------------------------
+// NCH = ceil(E / 256): each lane keeps NCH float4 of its row in registers, so the row is
+// read from HBM once.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x,
+                                                        const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta,
+                                                        float *out_f32, uint16_t *out_bf16, int M,
+                                                        int E, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float *src = x + (long)row * E;
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        v[c] = col < E ? *reinterpret_cast<const f32x4 *>(src + col) : f32x4{0, 0, 0, 0};
+        s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    }
+    const float mean = tc_wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < E) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[c][j] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(tc_wave_sum(q) / (float)E + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < E) {
+            const f32x4 g = *reinterpret_cast<const f32x4 *>(gamma + col);
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(beta + col);
+            f32x4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = (v[c][j] - mean) * rstd * g[j] + b[j];
+            if (out_f32) *reinterpret_cast<f32x4 *>(out_f32 + (long)row * E + col) = y;
+            if (out_bf16) {
+                u32x2 w;
+                w[0] = tc_pack_bf16(y[0], y[1]);
+                w[1] = tc_pack_bf16(y[2], y[3]);
+                *reinterpret_cast<u32x2 *>(out_bf16 + (long)row * E + col) = w;
+            }
+        }
+    }
+}
+
+// ---- key-validity words ------------------------------------------------------------------
+__global__ __launch_bounds__(64) void key_mask_kernel(const uint8_t *__restrict__ pad_flags,
+                                                      uint64_t *__restrict__ words, int T, int nw) {
+    const int b = blockIdx.y, w = blockIdx.x, lane = threadIdx.x;
+    const int key = w * 64 + lane;
+    const bool valid = key < T && pad_flags[(long)b * T + key] == 0;
+    const unsigned long long m = __ballot(valid);
+    if (lane == 0) words[(long)b * nw + w] = m;
+}
+
+// ---- LayerNorm + thin projection heads -------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void head_kernel(const T *__restrict__ g, int ldg, int col0,
+                                                   const float *__restrict__ gamma,
+                                                   const float *__restrict__ beta,
+                                                   const float *__restrict__ W,
+                                                   const float *__restrict__ bias,
+                                                   float *__restrict__ out, int M, int E, int V,
+                                                   float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T *src = g + (long)row * ldg + col0;
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < E) {
+            if constexpr (sizeof(T) == 2) {
+                const u32x2 w = *reinterpret_cast<const u32x2 *>(src + col);
+                v[c] = f32x4{tc_bf16_lo(w[0]), tc_bf16_hi(w[0]), tc_bf16_lo(w[1]), tc_bf16_hi(w[1])};
+            } else {
+                v[c] = *reinterpret_cast<const f32x4 *>(src + col);
+            }
+        } else {
+            v[c] = f32x4{0, 0, 0, 0};
+        }
+        s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    }
+    const float mean = tc_wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < E) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[c][j] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(tc_wave_sum(q) / (float)E + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < E) {
+            const f32x4 gm = *reinterpret_cast<const f32x4 *>(gamma + col);
+            const f32x4 bt = *reinterpret_cast<const f32x4 *>(beta + col);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[c][j] = (v[c][j] - mean) * rstd * gm[j] + bt[j];
+        }
+    }
+    float mine = 0.f;                               // lane o keeps logit o
+    for (int o = 0; o < V; ++o) {
+        const float *w = W + (long)o * E;
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < E) {
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + col);
+                d += v[c][0] * wv[0] + v[c][1] * wv[1] + v[c][2] * wv[2] + v[c][3] * wv[3];
+            }
+        }
+        d = tc_wave_sum(d);
+        if (lane == o) mine = d + bias[o];
+    }
+    if (lane < V) out[(long)row * V + lane] = mine;
+}
+
+// ---- greedy synonymous-codon decode ----------------------------------------------------------
+// Amino-acid code = index into "FLIMVPTAY_HQNKDECWRSG"; codons in the table order of the
+// reference; bases coded 0..3 = A,U,C,G (logit columns 5..8).
+__constant__ uint8_t kNumCodons[21] = {2, 6, 3, 1, 4, 4, 4, 4, 2, 3, 2, 2, 2, 2, 2, 2, 2, 1, 6, 6, 4};
+#define CD(a, b, c) (uint8_t)((a) | ((b) << 2) | ((c) << 4))
+enum { bA = 0, bU = 1, bC = 2, bG = 3 };
+__constant__ uint8_t kCodons[21][6] = {
+    /*F*/ {CD(bU, bU, bU), CD(bU, bU, bC)},
+    /*L*/ {CD(bU, bU, bA), CD(bU, bU, bG), CD(bC, bU, bU), CD(bC, bU, bC), CD(bC, bU, bA), CD(bC, bU, bG)},
+    /*I*/ {CD(bA, bU, bU), CD(bA, bU, bC), CD(bA, bU, bA)},
+    /*M*/ {CD(bA, bU, bG)},
+    /*V*/ {CD(bG, bU, bU), CD(bG, bU, bC), CD(bG, bU, bA), CD(bG, bU, bG)},
+    /*P*/ {CD(bC, bC, bU), CD(bC, bC, bC), CD(bC, bC, bA), CD(bC, bC, bG)},
+    /*T*/ {CD(bA, bC, bU), CD(bA, bC, bC), CD(bA, bC, bA), CD(bA, bC, bG)},
+    /*A*/ {CD(bG, bC, bU), CD(bG, bC, bC), CD(bG, bC, bA), CD(bG, bC, bG)},
+    /*Y*/ {CD(bU, bA, bU), CD(bU, bA, bC)},
+    /*_*/ {CD(bU, bA, bA), CD(bU, bA, bG), CD(bU, bG, bA)},
+    /*H*/ {CD(bC, bA, bU), CD(bC, bA, bC)},
+    /*Q*/ {CD(bC, bA, bA), CD(bC, bA, bG)},
+    /*N*/ {CD(bA, bA, bU), CD(bA, bA, bC)},
+    /*K*/ {CD(bA, bA, bA), CD(bA, bA, bG)},
+    /*D*/ {CD(bG, bA, bU), CD(bG, bA, bC)},
+    /*E*/ {CD(bG, bA, bA), CD(bG, bA, bG)},
+    /*C*/ {CD(bU, bG, bU), CD(bU, bG, bC)},
+    /*W*/ {CD(bU, bG, bG)},
+    /*R*/ {CD(bC, bG, bU), CD(bC, bG, bC), CD(bC, bG, bA), CD(bC, bG, bG), CD(bA, bG, bA), CD(bA, bG, bG)},
+    /*S*/ {CD(bA, bG, bU), CD(bA, bG, bC), CD(bU, bC, bU), CD(bU, bC, bC), CD(bU, bC, bA), CD(bU, bC, bG)},
+    /*G*/ {CD(bG, bG, bU), CD(bG, bG, bC), CD(bG, bG, bA), CD(bG, bG, bG)},
+};
+
+__global__ __launch_bounds__(256) void decode_kernel(const float *__restrict__ logits, int ldl,
+                                                     const uint8_t *__restrict__ aa,
+                                                     const int32_t *__restrict__ aa_off,
+                                                     const int32_t *__restrict__ row0,
+                                                     uint8_t *__restrict__ bases, int n_seq,
+                                                     int n_aa_total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;       // global residue index
+    if (i >= n_aa_total) return;
+    // sequence of residue i: aa_off is sorted, binary search for the last offset <= i
+    int lo = 0, hi = n_seq;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (aa_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int local = i - aa_off[lo];
+    const long row = (long)row0[lo] + 3L * local;
+    float pb[3][4];                                      // softmax probability of A,U,C,G per position
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float *l = logits + (row + j) * ldl;
+        float v[10];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 10; ++c) { v[c] = l[c]; mx = fmaxf(mx, v[c]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 10; ++c) {
+            // exp in f64 then one rounding to f32: keeps subnormal probabilities (the f32
+            // library exp flushes them), which decide ties between underflowing codons
+            v[c] = (float)exp((double)(v[c] - mx));
+            sum += v[c];
+        }
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pb[j][c] = v[5 + c] * inv;
+    }
+    const int a = aa[i];
+    const int nc = a < 21 ? kNumCodons[a] : 0;
+    double best = -INFINITY;
+    uint8_t pick = 0;
+    for (int c = 0; c < nc; ++c) {
+        const uint8_t cd = kCodons[a][c];
+        double pr = 1.0;
+        pr *= (double)pb[0][cd & 3];
+        pr *= (double)pb[1][(cd >> 2) & 3];
+        pr *= (double)pb[2][(cd >> 4) & 3];
+        if (pr > best) { best = pr; pick = cd; }
+    }
+    const char sym[4] = {'A', 'U', 'C', 'G'};
+    uint8_t *o = bases + 3L * i;
+    if (nc == 0) { o[0] = o[1] = o[2] = '?'; return; }
+    o[0] = sym[pick & 3];
+    o[1] = sym[(pick >> 2) & 3];
+    o[2] = sym[(pick >> 4) & 3];
+}
+
+// ---- cross-entropy over thin logits --------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_kernel(const float *__restrict__ logits,
+                                                 const int32_t *__restrict__ labels,
+                                                 float *loss_sum, int32_t *count, float *dlogits,
+                                                 float grad_scale, int M, int V) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    float loss = 0.f;
+    int cnt = 0;
+    if (row < M) {
+        const int y = labels[row];
+        const float *l = logits + (long)row * V;
+        if (y >= 0 && y < V) {
+            float mx = -INFINITY;
+            for (int c = 0; c < V; ++c) mx = fmaxf(mx, l[c]);
+            float sum = 0.f;
+            for (int c = 0; c < V; ++c) sum += expf(l[c] - mx);
+            const float lse = mx + logf(sum);
+            loss = lse - l[y];
+            cnt = 1;
+            if (dlogits) {
+                for (int c = 0; c < V; ++c)
+                    dlogits[(long)row * V + c] = (expf(l[c] - lse) - (c == y ? 1.f : 0.f)) * grad_scale;
+            }
+        } else if (dlogits) {
+            for (int c = 0; c < V; ++c) dlogits[(long)row * V + c] = 0.f;
+        }
+    }
+    loss = tc_wave_sum(loss);
+    const unsigned long long voted = __ballot(cnt != 0);
+    if ((threadIdx.x & 63) == 0) {
+        const int n = __popcll(voted);
+        if (n) {
+            atomicAdd(loss_sum, loss);
+            atomicAdd(count, n);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tc_embed_fwd(const int32_t *tokens, const int32_t *species, const float *tok_table,
+                            const float *species_table, float *x, uint8_t *pad_flags,
+                            int32_t *bad_index, int B, int T, int E, int vocab, int n_species,
+                            int pad_idx, void *stream) {
+    TC_REQUIRE(tokens && species && tok_table && species_table && x, "tc_embed_fwd: null operand");
+    TC_REQUIRE(B > 0 && T > 0 && E > 0 && E % 4 == 0, "tc_embed_fwd: bad shape B=%d T=%d E=%d", B, T, E);
+    TC_REQUIRE(tc_aligned16(tok_table) && tc_aligned16(species_table) && tc_aligned16(x),
+               "tc_embed_fwd: tables and output must be 16-byte aligned");
+    const long M = (long)B * T;
+    TC_REQUIRE(M < (1L << 31), "tc_embed_fwd: too many rows");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TcProfScope prof(TC_PROF_EMBED, s, (double)M * (4.0 + 4.0 * E));
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, tokens, species,
+                       tok_table, species_table, x, pad_flags, bad_index, (int)M, T, E, vocab,
+                       n_species, pad_idx);
+    TC_CHECK_LAUNCH("tc_embed_fwd");
+    return TC_OK;
+}
+
+extern "C" int tc_layernorm_fwd(const float *x, const float *gamma, const float *beta,
+                                float *out_f32, void *out_bf16, int M, int E, float eps,
+                                void *stream) {
+    TC_REQUIRE(x && gamma && beta && (out_f32 || out_bf16), "tc_layernorm_fwd: null operand");
+    TC_REQUIRE(M > 0 && E > 0 && E % 4 == 0 && E <= 2048, "tc_layernorm_fwd: bad shape M=%d E=%d", M, E);
+    TC_REQUIRE(tc_aligned16(x) && tc_aligned16(gamma) && tc_aligned16(beta) &&
+                   tc_aligned16(out_f32) && (((uintptr_t)out_bf16) & 7u) == 0,
+               "tc_layernorm_fwd: misaligned operand");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const double bytes = (double)M * E * (4.0 + (out_f32 ? 4.0 : 0.0) + (out_bf16 ? 2.0 : 0.0));
+    TcProfScope prof(TC_PROF_LAYERNORM, s, bytes);
+    const dim3 grid((M + 3) / 4), block(256);
+    uint16_t *ob = static_cast<uint16_t *>(out_bf16);
+    const int nch = (E + 255) / 256;
+#define TC_LN(N) hipLaunchKernelGGL(layernorm_kernel<N>, grid, block, 0, s, x, gamma, beta, out_f32, ob, M, E, eps)
+    switch (nch) {
+        case 1: TC_LN(1); break;
+        case 2: TC_LN(2); break;
+        case 3: TC_LN(3); break;
+        case 4: TC_LN(4); break;
+        default: TC_LN(8); break;
+    }
+#undef TC_LN
+    TC_CHECK_LAUNCH("tc_layernorm_fwd");
+    return TC_OK;
+}
+
+extern "C" int tc_key_mask_words(const uint8_t *pad_flags, uint64_t *words, int B, int T,
+                                 void *stream) {
+    TC_REQUIRE(pad_flags && words && B > 0 && T > 0, "tc_key_mask_words: bad arguments");
+    const int nw = (T + 63) / 64;
+    hipLaunchKernelGGL(key_mask_kernel, dim3(nw, B), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       pad_flags, words, T, nw);
+    TC_CHECK_LAUNCH("tc_key_mask_words");
+    return TC_OK;
+}
+
+extern "C" int tc_head_logits_fwd(int dtype, const void *g, int ldg, int col0, const float *gamma,
+                                  const float *beta, const float *W, const float *bias, float *out,
+                                  int M, int E, int V, float eps, void *stream) {
+    TC_REQUIRE(dtype == TC_BF16 || dtype == TC_F32, "tc_head_logits_fwd: bad dtype %d", dtype);
+    TC_REQUIRE(g && gamma && beta && W && bias && out, "tc_head_logits_fwd: null operand");
+    TC_REQUIRE(M > 0 && E > 0 && E % 4 == 0 && E <= 1024 && V > 0 && V <= 16,
+               "tc_head_logits_fwd: bad shape M=%d E=%d V=%d", M, E, V);
+    TC_REQUIRE(ldg % 4 == 0 && col0 % 4 == 0 && col0 + E <= ldg, "tc_head_logits_fwd: bad ldg/col0");
+    TC_REQUIRE(tc_aligned16(g) && tc_aligned16(gamma) && tc_aligned16(beta) && tc_aligned16(W),
+               "tc_head_logits_fwd: misaligned operand");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int esz = dtype == TC_BF16 ? 2 : 4;
+    TcProfScope prof(TC_PROF_HEAD, s, (double)M * (E * (double)esz + 4.0 * V));
+    const dim3 grid((M + 3) / 4), block(256);
+    const int nch = (E + 255) / 256;
+#define TC_HEAD(TY, N)                                                                          \
+    hipLaunchKernelGGL((head_kernel<TY, N>), grid, block, 0, s, static_cast<const TY *>(g), ldg, \
+                       col0, gamma, beta, W, bias, out, M, E, V, eps)
+    if (dtype == TC_BF16) {
+        switch (nch) {
+            case 1: TC_HEAD(uint16_t, 1); break;
+            case 2: TC_HEAD(uint16_t, 2); break;
+            case 3: TC_HEAD(uint16_t, 3); break;
+            default: TC_HEAD(uint16_t, 4); break;
+        }
+    } else {
+        switch (nch) {
+            case 1: TC_HEAD(float, 1); break;
+            case 2: TC_HEAD(float, 2); break;
+            case 3: TC_HEAD(float, 3); break;
+            default: TC_HEAD(float, 4); break;
+        }
+    }
+#undef TC_HEAD
+    TC_CHECK_LAUNCH("tc_head_logits_fwd");
+    return TC_OK;
+}
+
+extern "C" int tc_codon_decode(const float *logits, int ldl, const uint8_t *aa,
+                               const int32_t *aa_off, const int32_t *row0, uint8_t *bases,
+                               int n_seq, int n_aa_total, void *stream) {
+    TC_REQUIRE(logits && aa && aa_off && row0 && bases, "tc_codon_decode: null operand");
+    TC_REQUIRE(ldl >= 10 && n_seq > 0 && n_aa_total >= 0, "tc_codon_decode: bad shape");
+    if (n_aa_total == 0) return TC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TcProfScope prof(TC_PROF_DECODE, s, (double)n_aa_total * (120.0 + 3.0 + 1.0));
+    hipLaunchKernelGGL(decode_kernel, dim3((n_aa_total + 255) / 256), dim3(256), 0, s, logits, ldl, aa,
+                       aa_off, row0, bases, n_seq, n_aa_total);
+    TC_CHECK_LAUNCH("tc_codon_decode");
+    return TC_OK;
+}
+
+extern "C" int tc_ce_loss_fwd_bwd(const float *logits, const int32_t *labels, float *loss_sum,
+                                  int32_t *count, float *dlogits, float grad_scale, int M, int V,
+                                  void *stream) {
+    TC_REQUIRE(logits && labels && loss_sum && count, "tc_ce_loss_fwd_bwd: null operand");
+    TC_REQUIRE(M > 0 && V > 0 && V <= 64, "tc_ce_loss_fwd_bwd: bad shape M=%d V=%d", M, V);
+    hipLaunchKernelGGL(ce_kernel, dim3((M + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       logits, labels, loss_sum, count, dlogits, grad_scale, M, V);
+    TC_CHECK_LAUNCH("tc_ce_loss_fwd_bwd");
+    return TC_OK;
+}

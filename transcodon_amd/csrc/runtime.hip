@@ -1,0 +1,108 @@
+// Error reporting and per-kernel-family event timing for libtranscodon_hip.so.
+#include "common.h"
+
+#include <mutex>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+struct ProfSlot {
+    hipEvent_t start, stop;
+    int kind;
+    double work;
+    bool used;
+};
+
+struct ProfState {
+    std::mutex mu;
+    bool enabled = false;
+    std::vector<ProfSlot *> slots;      // recorded since the last reset
+    std::vector<ProfSlot *> free_slots; // events are recycled, never destroyed while loaded
+    int64_t launches[TC_PROF_NKINDS] = {};
+    double ms[TC_PROF_NKINDS] = {};
+    double work[TC_PROF_NKINDS] = {};
+} g_prof;
+
+}  // namespace
+
+void tc_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *tc_last_error(void) { return g_err; }
+extern "C" int tc_version(void) { return TC_VERSION; }
+
+TcProfScope::TcProfScope(int kind_, hipStream_t stream_, double work)
+    : kind(kind_), stream(stream_), slot(nullptr) {
+    if (!g_prof.enabled) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    ProfSlot *s;
+    if (!g_prof.free_slots.empty()) {
+        s = g_prof.free_slots.back();
+        g_prof.free_slots.pop_back();
+    } else {
+        s = new ProfSlot();
+        if (hipEventCreate(&s->start) != hipSuccess || hipEventCreate(&s->stop) != hipSuccess) {
+            delete s;
+            return;
+        }
+    }
+    s->kind = kind;
+    s->work = work;
+    s->used = hipEventRecord(s->start, stream) == hipSuccess;
+    g_prof.slots.push_back(s);
+    slot = s;
+}
+
+TcProfScope::~TcProfScope() {
+    if (!slot) return;
+    ProfSlot *s = static_cast<ProfSlot *>(slot);
+    if (s->used) s->used = hipEventRecord(s->stop, stream) == hipSuccess;
+}
+
+static void prof_drain_locked() {
+    for (ProfSlot *s : g_prof.slots) {
+        if (s->used && hipEventSynchronize(s->stop) == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s->start, s->stop) == hipSuccess) {
+                g_prof.launches[s->kind] += 1;
+                g_prof.ms[s->kind] += ms;
+                g_prof.work[s->kind] += s->work;
+            }
+        }
+        g_prof.free_slots.push_back(s);
+    }
+    g_prof.slots.clear();
+}
+
+extern "C" int tc_prof_enable(int enabled) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.enabled = enabled != 0;
+    return TC_OK;
+}
+
+extern "C" int tc_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    prof_drain_locked();
+    for (int k = 0; k < TC_PROF_NKINDS; ++k) {
+        g_prof.launches[k] = 0;
+        g_prof.ms[k] = 0.0;
+        g_prof.work[k] = 0.0;
+    }
+    return TC_OK;
+}
+
+extern "C" int tc_prof_collect(int kind, int64_t *launches, double *ms_total, double *work_total) {
+    TC_REQUIRE(kind >= 0 && kind < TC_PROF_NKINDS, "tc_prof_collect: bad kind %d", kind);
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    prof_drain_locked();
+    if (launches) *launches = g_prof.launches[kind];
+    if (ms_total) *ms_total = g_prof.ms[kind];
+    if (work_total) *work_total = g_prof.work[kind];
+    return TC_OK;
+}

@@ -1,0 +1,154 @@
+"""Codon optimisation driver: tokenise -> forward -> greedy synonymous-codon decode.
+
+``embed_sequence`` keeps the call contract of the reference's
+transcodon/infer_utr.py:17-159; ``AA_tokenize`` / ``back_translation_ok`` those of
+infer.py:76-88,113-129.  The decode itself (infer_utr.py:98-133, a triple Python loop with
+one softmax launch and one device->host copy per base) is a single kernel here
+(tc_codon_decode).  ``optimize_codons`` is the batched form: many proteins per forward,
+ragged CDS offsets, one decode launch.
+"""
+
+from typing import List, Optional, Sequence, Union
+
+import torch
+
+from . import ops
+from .alphabet import ORGANISM2ID, Alphabet
+from .sequence import CODON_TO_AA, CodonSequence_infer, WithUtr_CodonSequence_infer
+
+_ALPHABET = Alphabet.from_architecture("CodonModel")
+_CONVERTER = _ALPHABET.get_batch_converter()
+
+# first synonymous codon of every amino acid in the decode table's order
+_FIRST_CODON = {"F": "UUU", "I": "AUU", "M": "AUG", "V": "GUU", "P": "CCU", "T": "ACU", "A": "GCU",
+                "Y": "UAU", "_": "UAA", "H": "CAU", "Q": "CAA", "N": "AAU", "K": "AAA", "D": "GAU",
+                "E": "GAA", "C": "UGU", "W": "UGG", "G": "GGU"}
+
+
+def AA_tokenize(seq: str) -> str:
+    """CDS template of a protein whose last character stands for the stop codon: the two
+    bases shared by an amino acid's codons are given, the rest is '*' (masked)."""
+    parts = []
+    for ch in seq[:-1]:
+        if ch == "L":
+            parts.append("*U*")
+        elif ch == "R":
+            parts.append("*G*")
+        elif ch == "S":
+            parts.append("***")
+        else:
+            parts.append(_FIRST_CODON[ch][:2] + "*")      # KeyError for non-standard letters
+    parts.append("U**")
+    return "".join(parts)
+
+
+def back_translation_ok(rna: str, aa_seq: str) -> bool:
+    res = "".join(CODON_TO_AA[rna[i:i + 3]] for i in range(0, len(rna), 3))
+    return res[:-1] == aa_seq[:len(res)][:-1]
+
+
+def tokenize(seq) -> torch.Tensor:
+    _, _, tokens = _CONVERTER([("", seq.seq)])
+    return tokens
+
+
+def _species_id(species) -> int:
+    if isinstance(species, str):
+        return ORGANISM2ID[species]
+    if isinstance(species, int):
+        return species
+    raise ValueError("species_type_ids must be str or int")
+
+
+def _model_device(model):
+    return next(model.parameters()).device
+
+
+def embed_sequence(model, utr_seq, sequence: Union[str, WithUtr_CodonSequence_infer],
+                   species_type_ids: Union[int, str] = 0, AA_seq: str = "", average: bool = True):
+    """Returns (representations, logits sliced to the CDS [1, 3m(+), vocab], predicted RNA)."""
+    if isinstance(sequence, str):
+        seq = CodonSequence_infer(sequence) if utr_seq == "false" else \
+            WithUtr_CodonSequence_infer(utr_seq, sequence)
+    elif isinstance(sequence, (WithUtr_CodonSequence_infer, CodonSequence_infer)):
+        seq = sequence
+    else:
+        raise ValueError("Input sequence must be string or CodonSequence.")
+    dev = _model_device(model)
+    species = torch.tensor([_species_id(species_type_ids)], device=dev)
+    tokens = tokenize(seq).to(dev)
+    with torch.no_grad():
+        output = model(tokens, species)
+    logits = output["logits"]
+    start = 1 + (0 if utr_seq == "false" else len(utr_seq) + 1)
+    cds_logits = logits[:, start:-1, :]
+    T = tokens.shape[1]
+    m = len(AA_seq)
+    if 3 * m > T - 1 - start:
+        raise IndexError("AA_seq is longer than the CDS part of the sequence")
+    aa = torch.tensor(list(ops.encode_amino_acids(AA_seq)), dtype=torch.uint8, device=dev)
+    off = torch.tensor([0, m], dtype=torch.int32, device=dev)
+    row0 = torch.tensor([start], dtype=torch.int32, device=dev)
+    bases = ops.codon_decode(logits.view(T, -1), aa, off, row0)
+    rna = bytes(bases.cpu().numpy()).decode("ascii")
+    return output["representations"], cds_logits, rna
+
+
+def optimize_codons(model, proteins: Sequence[str], organisms: Sequence[Union[int, str]],
+                    utrs: Optional[Sequence[str]] = None, max_batch_tokens: int = 1 << 17,
+                    max_aa: int = 2048) -> List[str]:
+    """Batched codon optimisation: RNA string per protein (stop codon included).
+
+    Proteins are given without the stop marker; like infer.py:262-269 a '_' is appended and
+    templates longer than 3*max_aa bases are truncated.  Sequences are sorted by length and
+    packed into padded batches of at most ``max_batch_tokens`` tokens."""
+    dev = _model_device(model)
+    items = []
+    for i, prot in enumerate(proteins):
+        aa = prot + "_"
+        tmpl = AA_tokenize(aa)
+        if len(tmpl) > 3 * max_aa:
+            aa, tmpl = aa[:max_aa], tmpl[:3 * max_aa]
+        utr = None if utrs is None else utrs[i]
+        seq = CodonSequence_infer(tmpl) if utr is None else WithUtr_CodonSequence_infer(utr, tmpl)
+        ids = _ALPHABET.encode(seq.seq)
+        start = 1 + (0 if utr is None else len(utr.replace(" ", "")) + 1)
+        items.append((i, ids, start, aa, _species_id(organisms[i])))
+    order = sorted(range(len(items)), key=lambda k: len(items[k][1]))
+    out: List[Optional[str]] = [None] * len(items)
+    pos = 0
+    while pos < len(order):
+        width = 0
+        chunk = []
+        while pos < len(order):
+            cand = items[order[pos]]
+            w = max(width, len(cand[1]))
+            if chunk and w * (len(chunk) + 1) > max_batch_tokens:
+                break
+            chunk.append(cand)
+            width = w
+            pos += 1
+        B = len(chunk)
+        tok = torch.full((B, width), _ALPHABET.padding_idx, dtype=torch.int32)
+        for r, (_, ids, _, _, _) in enumerate(chunk):
+            tok[r, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+        species = torch.tensor([c[4] for c in chunk], dtype=torch.int32)
+        aa_all = b"".join(ops.encode_amino_acids(c[3]) for c in chunk)
+        offs = [0]
+        for c in chunk:
+            offs.append(offs[-1] + len(c[3]))
+        row0 = [r * width + c[2] for r, c in enumerate(chunk)]
+        with torch.no_grad():
+            logits = model(tok.to(dev), species.to(dev))["logits"]
+        bases = ops.codon_decode(
+            logits.view(B * width, -1),
+            torch.frombuffer(bytearray(aa_all), dtype=torch.uint8).to(dev),
+            torch.tensor(offs, dtype=torch.int32, device=dev),
+            torch.tensor(row0, dtype=torch.int32, device=dev))
+        flat = bytes(bases.cpu().numpy()).decode("ascii")
+        for r, c in enumerate(chunk):
+            rna = flat[3 * offs[r]:3 * offs[r + 1]]
+            if not back_translation_ok(rna, c[3]):
+                raise RuntimeError(f"prediction for sequence {c[0]} does not translate back to its protein")
+            out[c[0]] = rna
+    return out

@@ -1,0 +1,235 @@
+"""ProteinBertModel on the MI355X kernels.
+
+Same constructor (args namespace + alphabet), ``add_args``, parameter names / state_dict
+keys and forward contract as the reference's transcodon/model.py:30-263.  The forward of a
+padded batch is ONE call into libtranscodon_hip.so (tc_encoder_forward); PyTorch only owns
+the parameters, the output buffers and the stream.
+"""
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+from ._lib import EncoderDesc, LayerWeights, check
+from .modules import (ESM1bLayerNorm, RNA_2D_RobertaLMHead, RNA_2D_Structure_Connector,
+                      RobertaLMHead, TransformerLayer)
+from .multihead_attention import _param_key
+
+
+class ProteinBertModel(nn.Module):
+    @classmethod
+    def add_args(cls, parser):
+        parser.add_argument("--num_layers", default=12, type=int, metavar="N", help="number of layers")
+        parser.add_argument("--embed_dim", default=768, type=int, metavar="N", help="embedding dimension")
+        parser.add_argument("--attention_dropout", default=0.0, type=float, help="dropout on attention")
+        parser.add_argument("--logit_bias", action="store_true", help="whether to apply bias to logits")
+        parser.add_argument("--rope_embedding", default=True, type=_flag, help="use rotary embeddings")
+        parser.add_argument("--ffn_embed_dim", default=768 * 4, type=int, metavar="N", help="FFN width")
+        parser.add_argument("--attention_heads", default=12, type=int, metavar="N", help="attention heads")
+        parser.add_argument("--species_embedding", default=True, type=_flag, help="add species embedding")
+        parser.add_argument("--struct_label", default=True, type=_flag, help="structure head")
+        parser.add_argument("--species_vocab_size", default=1438, type=int, metavar="N",
+                            help="species_vocab_size")
+
+    def __init__(self, args, alphabet):
+        super().__init__()
+        self.args = args
+        self.alphabet_size = len(alphabet)
+        self.padding_idx = alphabet.padding_idx
+        self.mask_idx = alphabet.mask_idx
+        self.cls_idx = alphabet.cls_idx
+        self.eos_idx = alphabet.eos_idx
+        self.prepend_bos = alphabet.prepend_bos
+        self.append_eos = alphabet.append_eos
+        self.model_version = "ESM-1b"
+        if not getattr(args, "rope_embedding", True):
+            raise NotImplementedError("learned positional embeddings are not built (rope only)")
+        if not getattr(args, "species_embedding", True):
+            raise NotImplementedError("the species embedding is always on in this build")
+        if getattr(args, "token_dropout", False) or getattr(args, "emb_layer_norm_before", False):
+            raise NotImplementedError("token_dropout / emb_layer_norm_before are not built")
+        if getattr(args, "attention_dropout", 0.0):
+            raise NotImplementedError("attention dropout is not built (the reference trains with 0)")
+        E = args.embed_dim
+        self.embed_scale = 1
+        self.embed_tokens = nn.Embedding(self.alphabet_size, E, padding_idx=self.padding_idx)
+        self.species_embedding = nn.Embedding(args.species_vocab_size, E)
+        # parameters that live in checkpoints but are never used by forward (model.py:114-134)
+        self.struct_linear1 = nn.Linear(E, E)
+        self.struct_linear2 = nn.Linear(E, E)
+        self.struct_linear3 = nn.Linear(E, E)
+        self.connector = RNA_2D_Structure_Connector(E)
+        self.norm = ESM1bLayerNorm(E)
+        self.existence_head = nn.Sequential(nn.Linear(E, 128), nn.ReLU(), nn.Linear(128, 1))
+        self.layers = nn.ModuleList([
+            TransformerLayer(E, args.ffn_embed_dim, args.attention_heads,
+                             attention_dropout=0.0, add_bias_kv=False, use_esm1b_layer_norm=True,
+                             rope_embedding=True)
+            for _ in range(args.num_layers)])
+        self.emb_layer_norm_after = ESM1bLayerNorm(E)
+        self.lm_head = RobertaLMHead(embed_dim=E, output_dim=self.alphabet_size,
+                                     weight=self.embed_tokens.weight)
+        self.structure_linear = RNA_2D_RobertaLMHead(embed_dim=E, output_dim=3)
+        self.compute_dtype = None       # None: follow the parameter dtype (f32 unless .bfloat16())
+        self.check_indices = True       # raise IndexError on out-of-range token / species ids
+        self._pack = {}
+        self._workspace = None
+
+    @property
+    def num_layers(self):
+        return self.args.num_layers
+
+    def set_compute_dtype(self, dtype):
+        """torch.bfloat16 (MFMA bf16 operands, fp32 accumulate) or torch.float32 (exact f32)."""
+        assert dtype in (None, torch.float32, torch.bfloat16)
+        for m in self.modules():
+            if hasattr(m, "compute_dtype"):
+                m.compute_dtype = dtype
+        return self
+
+    def _dtype(self):
+        return self.compute_dtype or (torch.bfloat16 if self.embed_tokens.weight.dtype == torch.bfloat16
+                                      else torch.float32)
+
+    # -- device-side weight pack and descriptor --------------------------------------------
+    def _packed(self, dtype, T, device):
+        own = [self.embed_tokens.weight, self.species_embedding.weight,
+               self.emb_layer_norm_after.weight, self.emb_layer_norm_after.bias,
+               self.lm_head.dense.weight, self.lm_head.dense.bias, self.lm_head.layer_norm.weight,
+               self.lm_head.layer_norm.bias, self.lm_head.bias,
+               self.structure_linear.dense.weight, self.structure_linear.dense.bias,
+               self.structure_linear.layer_norm.weight, self.structure_linear.layer_norm.bias,
+               self.structure_linear.out_proj.weight, self.structure_linear.out_proj.bias,
+               self.structure_linear.bias]
+        layer_params = [p for l in self.layers for p in l.parameters()]
+        rope_len = max(512, 1 << (T - 1).bit_length())
+        key = (dtype, str(device), rope_len, _param_key(own + layer_params))
+        if self._pack.get("key") == key:
+            return self._pack
+        with torch.no_grad():
+            f = lambda p: p.detach().float().contiguous()
+            keep = {
+                "tok": f(own[0]), "sp": f(own[1]), "lnf_g": f(own[2]), "lnf_b": f(own[3]),
+                "w_heads": torch.cat([own[4].detach(), own[9].detach()]).to(dtype).contiguous(),
+                "b_heads": torch.cat([own[5].detach(), own[10].detach()]).float().contiguous(),
+                "lm_ln_g": f(own[6]), "lm_ln_b": f(own[7]), "lm_bias": f(own[8]),
+                "st_ln_g": f(own[11]), "st_ln_b": f(own[12]), "st_w": f(own[13]),
+                "st_bias": (own[14].detach().float() + own[15].detach().float()).contiguous(),
+            }
+            layers = (LayerWeights * len(self.layers))()
+            per_layer = []
+            for i, l in enumerate(self.layers):
+                pk = l.packed(dtype)
+                cos, sin = l.self_attn.rope.tables(rope_len, device)
+                per_layer.append((pk, cos, sin))
+                for name in ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_g", "ln2_b",
+                             "w_fc1", "b_fc1", "w_fc2", "b_fc2"):
+                    setattr(layers[i], name, pk[name].data_ptr())
+                layers[i].rope_cos, layers[i].rope_sin = cos.data_ptr(), sin.data_ptr()
+            d = EncoderDesc()
+            d.dtype = _lib.TC_BF16 if dtype == torch.bfloat16 else _lib.TC_F32
+            d.num_layers, d.E, d.F = len(self.layers), self.args.embed_dim, self.args.ffn_embed_dim
+            d.H, d.vocab = self.args.attention_heads, self.alphabet_size
+            d.n_species, d.n_struct, d.pad_idx = self.args.species_vocab_size, 3, self.padding_idx
+            d.rope_table_len, d.ln_eps = rope_len, self.emb_layer_norm_after.eps
+            d.tok_table, d.species_table = keep["tok"].data_ptr(), keep["sp"].data_ptr()
+            d.layers = C.cast(layers, C.POINTER(LayerWeights))
+            for name in ("lnf_g", "lnf_b", "w_heads", "b_heads", "lm_ln_g", "lm_ln_b", "lm_bias",
+                         "st_ln_g", "st_ln_b", "st_w", "st_bias"):
+                setattr(d, name, keep[name].data_ptr())
+        self._pack = {"key": key, "desc": d, "layers": layers, "keep": keep, "per_layer": per_layer}
+        return self._pack
+
+    def _get_workspace(self, nbytes, device):
+        ws = self._workspace
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            self._workspace = None
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._workspace = ws
+        return ws
+
+    # -- forward ---------------------------------------------------------------------------
+    def forward(self, tokens, species_type_ids, repr_layers=[12], need_head_weights=False):
+        assert tokens.ndim == 2
+        if not tokens.is_cuda:
+            raise _lib.HipLibraryError(
+                "ProteinBertModel.forward runs on the MI355X kernels only: move the model and "
+                "its inputs to the GPU (there is no CPU fallback)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "autograd through the HIP forward is not built yet: call under torch.no_grad()")
+        if need_head_weights:
+            return self._forward_with_attentions(tokens, species_type_ids, repr_layers)
+        B, T = tokens.shape
+        dev = tokens.device
+        L, E = len(self.layers), self.args.embed_dim
+        dt = self._dtype()
+        pk = self._packed(dt, T, dev)
+        lib = _lib.load()
+        tok32 = tokens.to(torch.int32).contiguous()
+        sp32 = species_type_ids.to(device=dev, dtype=torch.int32).contiguous()
+        assert sp32.numel() == B
+        logits = torch.empty(B, T, self.alphabet_size, dtype=torch.float32, device=dev)
+        struct = torch.empty(B, T, 3, dtype=torch.float32, device=dev)
+        repr_layers = set(repr_layers)
+        reps = {i: torch.empty(B, T, E, dtype=torch.float32, device=dev)
+                for i in sorted(repr_layers) if 0 <= i <= L}
+        mids = [i for i in reps if i < L]
+        rep_idx = (C.c_int32 * max(1, len(mids)))(*mids)
+        rep_ptr = (C.c_void_p * max(1, len(mids)))(*[reps[i].data_ptr() for i in mids])
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        need = lib.tc_workspace_bytes(C.byref(pk["desc"]), B, T)
+        ws = self._get_workspace(need, dev)
+        check(lib.tc_encoder_forward(
+            C.byref(pk["desc"]), tok32.data_ptr(), sp32.data_ptr(), B, T, logits.data_ptr(),
+            struct.data_ptr(), reps[L].data_ptr() if L in reps else None, len(mids), rep_idx,
+            rep_ptr, status.data_ptr(), ws.data_ptr(), ws.numel(),
+            torch.cuda.current_stream().cuda_stream), "tc_encoder_forward")
+        if self.check_indices and int(status.item()) != 0:
+            raise IndexError("token or species id out of range")
+        return {"logits": logits, "struct_label_output": struct, "representations": reps}
+
+    def _forward_with_attentions(self, tokens, species_type_ids, repr_layers):
+        """Layer-by-layer path for need_head_weights=True (model.py:213-256): also returns
+        ``attentions`` [B, L, H, T, T] = pre-softmax scores times the pad outer product."""
+        B, T = tokens.shape
+        L, E = len(self.layers), self.args.embed_dim
+        x, pad, bad = ops.embed(tokens, species_type_ids.to(tokens.device), self.embed_tokens.weight.detach().float(),
+                                self.species_embedding.weight.detach().float(), self.padding_idx)
+        if self.check_indices and int(bad.item()) != 0:
+            raise IndexError("token or species id out of range")
+        repr_layers = set(repr_layers)
+        reps = {}
+        x = x.view(B, T, E)
+        if 0 in repr_layers:
+            reps[0] = x
+        padding_mask = pad.view(B, T).bool()
+        kpm = padding_mask if bool(padding_mask.any()) else None
+        x = x.transpose(0, 1)
+        attn = []
+        for i, layer in enumerate(self.layers):
+            x, a = layer(x, self_attn_padding_mask=kpm, need_head_weights=True)
+            if (i + 1) in repr_layers:
+                reps[i + 1] = x.transpose(0, 1)
+            attn.append(a.transpose(1, 0))
+        x = self.emb_layer_norm_after(x).transpose(0, 1).contiguous()
+        if L in repr_layers:
+            reps[L] = x
+        out = {"logits": self.lm_head(x), "struct_label_output": self.structure_linear(x),
+               "representations": reps}
+        attentions = torch.stack(attn, 1)
+        if kpm is not None:
+            m = 1 - kpm.type_as(attentions)
+            m = m.unsqueeze(1) * m.unsqueeze(2)
+            attentions = attentions * m[:, None, None, :, :]
+        out["attentions"] = attentions
+        return out
+
+
+def _flag(v):
+    """Boolean command-line value that can actually be switched off."""
+    if isinstance(v, bool):
+        return v
+    return str(v).strip().lower() not in ("0", "false", "no", "off", "")

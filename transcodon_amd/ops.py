@@ -1,0 +1,148 @@
+"""Torch-tensor front ends of the C-ABI kernels (device pointers + current HIP stream).
+
+PyTorch only provides device memory and the stream here; all arithmetic runs in
+libtranscodon_hip.so.  Every function requires CUDA(HIP) tensors and raises otherwise.
+"""
+
+import torch
+
+from . import _lib
+from ._lib import TC_BF16, TC_F32, check
+
+AA_ORDER = "FLIMVPTAY_HQNKDECWRSG"      # amino-acid codes of tc_codon_decode
+_AA_CODE = {c: i for i, c in enumerate(AA_ORDER)}
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return TC_BF16
+    if t.dtype == torch.float32:
+        return TC_F32
+    raise TypeError(f"unsupported element type {t.dtype}")
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.HipLibraryError("transcodon_amd kernels need tensors on the GPU (no CPU fallback)")
+        if t is not None and not t.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def embed(tokens, species, tok_table, species_table, pad_idx=1):
+    """x[B*T,E] f32, pad_flags[B*T] u8, bad[1] i32   (model.py:178-206)."""
+    tokens = tokens.to(torch.int32).contiguous()
+    species = species.to(torch.int32).contiguous()
+    _dev(tokens, species, tok_table, species_table)
+    B, T = tokens.shape
+    E = tok_table.shape[1]
+    x = torch.empty(B * T, E, dtype=torch.float32, device=tokens.device)
+    pad = torch.empty(B * T, dtype=torch.uint8, device=tokens.device)
+    bad = torch.zeros(1, dtype=torch.int32, device=tokens.device)
+    check(_lib.load().tc_embed_fwd(_p(tokens), _p(species), _p(tok_table), _p(species_table), _p(x),
+                                   _p(pad), _p(bad), B, T, E, tok_table.shape[0],
+                                   species_table.shape[0], pad_idx, _stream()), "tc_embed_fwd")
+    return x, pad, bad
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out_dtype=torch.float32):
+    _dev(x, gamma, beta)
+    M, E = x.shape
+    out = torch.empty(M, E, dtype=out_dtype, device=x.device)
+    f32 = out if out_dtype == torch.float32 else None
+    b16 = out if out_dtype == torch.bfloat16 else None
+    check(_lib.load().tc_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(f32), _p(b16), M, E, eps,
+                                       _stream()), "tc_layernorm_fwd")
+    return out
+
+
+def gemm(a, w, bias, epilogue=_lib.EPI_BIAS, residual=None, out=None, q_scale=1.0,
+         rope_cos=None, rope_sin=None, T=0, head_dim=0):
+    """epilogue(a[M,K] @ w[N,K]^T + bias[N]); see tc_gemm."""
+    _dev(a, w, bias, residual, out, rope_cos, rope_sin)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.dtype == w.dtype
+    if out is None:
+        odt = torch.float32 if epilogue == _lib.EPI_BIAS_RESIDUAL else a.dtype
+        out = torch.empty(M, N, dtype=odt, device=a.device)
+    check(_lib.load().tc_gemm(_dt(a), epilogue, _p(a), a.stride(0), _p(w), _p(bias), _p(residual),
+                              _p(out), out.stride(0), M, N, K, q_scale, _p(rope_cos), _p(rope_sin),
+                              T, head_dim, _stream()), "tc_gemm")
+    return out
+
+
+def key_mask_words(pad_flags, B, T):
+    _dev(pad_flags)
+    words = torch.empty(B, (T + 63) // 64, dtype=torch.int64, device=pad_flags.device)
+    check(_lib.load().tc_key_mask_words(_p(pad_flags), _p(words), B, T, _stream()), "tc_key_mask_words")
+    return words
+
+
+def attention(qkv, B, T, H, key_words=None):
+    """qkv[B*T, 3*H*64] (q scaled, q/k rotated) -> out[B*T, H*64]."""
+    _dev(qkv, key_words)
+    E = H * 64
+    out = torch.empty(B * T, E, dtype=qkv.dtype, device=qkv.device)
+    check(_lib.load().tc_attn_fwd(_dt(qkv), _p(qkv), qkv.stride(0), _p(key_words), _p(out), B, T, H, 64,
+                                  _stream()), "tc_attn_fwd")
+    return out
+
+
+def attention_scores(qkv, B, T, H, pad_flags=None):
+    _dev(qkv, pad_flags)
+    s = torch.empty(B, H, T, T, dtype=torch.float32, device=qkv.device)
+    check(_lib.load().tc_attn_scores(_dt(qkv), _p(qkv), qkv.stride(0), _p(pad_flags), _p(s), B, T, H, 64,
+                                     _stream()), "tc_attn_scores")
+    return s
+
+
+def head_logits(g, col0, E, gamma, beta, W, bias, eps=1e-5):
+    _dev(g, gamma, beta, W, bias)
+    M = g.shape[0]
+    V = W.shape[0]
+    out = torch.empty(M, V, dtype=torch.float32, device=g.device)
+    check(_lib.load().tc_head_logits_fwd(_dt(g), _p(g), g.stride(0), col0, _p(gamma), _p(beta), _p(W),
+                                         _p(bias), _p(out), M, E, V, eps, _stream()),
+          "tc_head_logits_fwd")
+    return out
+
+
+def encode_amino_acids(aa_seq: str) -> bytes:
+    """Protein letters -> tc_codon_decode codes; unknown letters raise KeyError like
+    the reference's dict lookup (infer_utr.py:108)."""
+    return bytes(_AA_CODE[c] for c in aa_seq)
+
+
+def codon_decode(logits2d, aa_codes, aa_off, row0):
+    """logits2d f32 [rows, >=10]; aa_codes u8 [n]; aa_off i32 [n_seq+1]; row0 i32 [n_seq]
+    -> bases u8 [3n] (ASCII).  See tc_codon_decode."""
+    _dev(logits2d, aa_codes, aa_off, row0)
+    assert logits2d.dtype == torch.float32
+    n = aa_codes.numel()
+    bases = torch.empty(3 * n, dtype=torch.uint8, device=logits2d.device)
+    check(_lib.load().tc_codon_decode(_p(logits2d), logits2d.stride(0), _p(aa_codes), _p(aa_off),
+                                      _p(row0), _p(bases), row0.numel(), n, _stream()),
+          "tc_codon_decode")
+    return bases
+
+
+def ce_loss(logits2d, labels, want_grad=False, grad_scale=1.0):
+    """Returns (loss_sum f32[1], count i32[1], dlogits or None); mean = sum / count."""
+    labels = labels.to(torch.int32).contiguous()
+    _dev(logits2d, labels)
+    M, V = logits2d.shape
+    loss = torch.zeros(1, dtype=torch.float32, device=logits2d.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=logits2d.device)
+    dl = torch.empty_like(logits2d) if want_grad else None
+    check(_lib.load().tc_ce_loss_fwd_bwd(_p(logits2d), _p(labels), _p(loss), _p(cnt), _p(dl),
+                                         grad_scale, M, V, _stream()), "tc_ce_loss_fwd_bwd")
+    return loss, cnt, dl
