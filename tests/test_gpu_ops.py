@@ -99,6 +99,60 @@ def test_gemm_qkv_rope(dtype):
     np.testing.assert_allclose(out.numpy(), ref.numpy(), **tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(22037, 768, 768), (16384 + 5, 2304, 768), (33000, 512, 3072)])
+def test_gemm_large_tile_kernel(dtype, M, N, K):
+    """Shapes with >= 256 tiles of 256 x 256 take the persistent large-tile kernel; M is not a
+    multiple of the tile so the row tail is exercised.  All four epilogues."""
+    B_T = 61                                  # "sequence length" for the rotary positions
+    a, w, b = _rand(M, K, seed=31), _rand(N, K, seed=32, scale=0.05), _rand(N, seed=33)
+    if dtype == torch.bfloat16:
+        a, w = _bf(a), _bf(w)
+    y = (a @ w.t() + b)                       # fp32 CPU reference
+    tol = dict(rtol=1e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=5e-5, atol=5e-5)
+    ad, wd, bd = a.to(DEV, dtype), w.to(DEV, dtype), b.to(DEV)
+    out = ops.gemm(ad, wd, bd, _lib.EPI_BIAS).float().cpu()
+    np.testing.assert_allclose(out.numpy(), y.numpy(), **tol)
+    out = ops.gemm(ad, wd, bd, _lib.EPI_BIAS_GELU).float().cpu()
+    np.testing.assert_allclose(out.numpy(), O.gelu(y).numpy(), **tol)
+    r = _rand(M, N, seed=34)
+    res = r.to(DEV).clone()
+    ops.gemm(ad, wd, bd, _lib.EPI_BIAS_RESIDUAL, residual=res, out=res)
+    np.testing.assert_allclose(res.cpu().numpy(), (r + y).numpy(), **tol)
+    if N % 3 == 0 and (N // 3) % 64 == 0:
+        E, D = N // 3, 64
+        freqs = O.rope_freqs(D)
+        ang = torch.arange(B_T, dtype=torch.float32)[:, None] * freqs[None, :]
+        out = ops.gemm(ad, wd, bd, _lib.EPI_QKV_ROPE, q_scale=0.125, rope_cos=ang.cos().contiguous().to(DEV),
+                       rope_sin=ang.sin().contiguous().to(DEV), T=B_T, head_dim=D).float().cpu()
+        pos = torch.arange(M) % B_T
+        cs, sn = ang.cos()[pos].repeat_interleave(2, -1), ang.sin()[pos].repeat_interleave(2, -1)   # [M,64]
+
+        def rot(t):
+            t = t.view(M, E // D, D)
+            rh = torch.stack((-t[..., 1::2], t[..., 0::2]), -1).reshape(t.shape)
+            return (t * cs[:, None, :] + rh * sn[:, None, :]).reshape(M, E)
+
+        ref = torch.cat([rot(y[:, :E] * 0.125), rot(y[:, E:2 * E]), y[:, 2 * E:]], 1)
+        np.testing.assert_allclose(out.numpy(), ref.numpy(), **tol)
+
+
+def test_gelu_fast_accuracy():
+    """The bf16 GEMM epilogue uses a rational erf; check it against exact erf on a dense grid
+    by running a GEMM with an identity weight (values land on the bf16 grid, error <= 1 bf16 ulp)."""
+    K = N = 256
+    M = 65536
+    x = torch.linspace(-9, 9, M * K).view(M, K)
+    xb = _bf(x)
+    eye = torch.eye(N, K)
+    out = ops.gemm(xb.to(DEV, torch.bfloat16), eye.to(DEV, torch.bfloat16), torch.zeros(N, device=DEV),
+                   _lib.EPI_BIAS_GELU).float().cpu()
+    ref = O.gelu(xb.double()).float()
+    err = (out - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + 1e-6
+    assert bool((err <= bound).all()), float((err - bound).max())
+
+
 def test_gemm_rejects_bad_shapes():
     a = torch.zeros(8, 64, device=DEV, dtype=torch.bfloat16)
     w = torch.zeros(100, 64, device=DEV, dtype=torch.bfloat16)

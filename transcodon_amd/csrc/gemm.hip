@@ -1,30 +1,32 @@
 // out[M,N] = epilogue(A[M,K] . W[N,K]^T + bias) on the gfx950 matrix cores.
 //
-// One 256-thread workgroup (4 waves, 2 x 2) owns a 128 x 128 output tile; every wave owns
-// 64 x 64 of it as 4 x 4 MFMA 16x16 tiles.  Both operands are K-contiguous, so a k-tile is
-// 128 rows x 128 BYTES for either element type (64 bf16 or 32 f32 per row), and the
-// staging, swizzle and fragment addressing below are written in bytes and shared by both.
+// Both operands are K-contiguous, so a k-tile is 128 BYTES per row for either element type
+// (64 bf16 or 32 f32); staging, swizzle and fragment addressing are written in bytes and
+// shared by both.  MFMA: mfma_f32_16x16x32_bf16, or four mfma_f32_16x16x4_f32 per 16-byte
+// fragment for f32 (exact f32 multiply-add chain).
 //
 // Staging: global -> LDS by direct loads (global_load_lds_dwordx4): one wave instruction
-// writes 1 KiB = 8 rows x 128 B linearly.  Bank conflicts of the later ds_read_b128
-// fragment reads are avoided by an XOR swizzle of the 16-byte chunk index with (row & 7),
-// applied on the per-lane SOURCE address and again on the read address.
-// Two LDS stages: the loads of k-tile t+1 are in flight while tile t is multiplied.
+// writes 1 KiB = 8 rows x 128 B linearly.  Bank conflicts of the ds_read_b128 fragment
+// reads are avoided by an XOR swizzle of the 16-byte chunk index with (row & 7), applied on
+// the per-lane SOURCE address and again on the read address.  Two LDS stages: the loads of
+// k-tile t+1 are in flight while tile t is multiplied.
 //
-// Epilogue: each wave parks its 64 x 64 f32 accumulators in its private LDS region and
-// reads them back row-wise, 8 consecutive columns per lane, so that bias / GELU /
-// residual / rotary arithmetic works on contiguous columns and global stores are 16 bytes.
+// Two kernels share that machinery:
+//   gemm256_kernel  256 x 256 tile, 8 waves (2 x 4, 128 x 64 each), one persistent workgroup
+//                   per CU walking its share of the tiles; the first k-tile of the next tile
+//                   is already in flight during the epilogue.  The per-CU global->LDS path
+//                   moves half the bytes per flop of the small tile, which is what bounds
+//                   these GEMMs (K = 768 is short, so L2->LDS traffic, not HBM, is the limit).
+//   gemm128_kernel  128 x 128 tile, 4 waves (2 x 2, 64 x 64 each), two workgroups per CU;
+//                   used for small M, for N not a multiple of 256.
+//
+// Epilogue: accumulators go through a wave-private LDS patch and come back row-wise, 8 or 16
+// consecutive columns per lane, so that bias / GELU / residual / rotary arithmetic works on
+// contiguous columns and global accesses are 16 bytes.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
-
-constexpr int BM = 128, BN = 128;
-constexpr int TILE_BYTES = 128 * 128;          // one operand k-tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
-constexpr int CST_LD = 68;                     // f32 per staged C row (64 + 4 pad)
-constexpr int CST_WAVE_BYTES = 64 * CST_LD * 4;
-constexpr int GEMM_LDS_BYTES = (4 * CST_WAVE_BYTES > 2 * STAGE_BYTES) ? 4 * CST_WAVE_BYTES
-                                                                       : 2 * STAGE_BYTES;
 
 struct GemmParams {
     const char *A;
@@ -41,42 +43,47 @@ struct GemmParams {
     int nk;          // number of 128-byte k-tiles
     int T, head_dim, E;
     float q_scale;
+    int gm;          // large-tile kernel: row panels per ordering group (1 = n-fastest)
+#ifdef TC_GEMM_STAMPS
+    unsigned long long *stamps;   // per workgroup: wait, issue, math, epilogue cycles (wave 0)
+#endif
 };
 
+#ifdef TC_GEMM_STAMPS
+#define TC_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#else
+#define TC_STAMP(var)
+#endif
 
 __device__ __forceinline__ void glds16(const char *src, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(src), TC_LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
-template <typename T>
-__device__ __forceinline__ void mma_step(const f32x4 (&a)[4], const f32x4 (&b)[4],
-                                         f32x4 (&acc)[4][4]);
-
-// bf16: the 16 bytes of a fragment are 8 bf16 = one 16x16x32 operand.
-template <>
-__device__ __forceinline__ void mma_step<__bf16>(const f32x4 (&a)[4], const f32x4 (&b)[4],
-                                                 f32x4 (&acc)[4][4]) {
+// One k-step (16 bytes of K per row) of an MT x NT grid of 16x16 MFMA tiles.
+template <typename T, int MT, int NT>
+__device__ __forceinline__ void mma_step(const f32x4 (&a)[MT], const f32x4 (&b)[NT],
+                                         f32x4 (&acc)[MT][NT]) {
+    if constexpr (sizeof(T) == 2) {
+        // the 16 bytes of a fragment are 8 bf16 = one 16x16x32 operand
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni],
-                0, 0, 0);
-}
-// f32: the 16 bytes are 4 consecutive k of one row; MFMA j of the group of four takes
-// element j from both operands, i.e. k-slot g of MFMA j stands for k = 4g + j in A and B alike.
-template <>
-__device__ __forceinline__ void mma_step<float>(const f32x4 (&a)[4], const f32x4 (&b)[4],
-                                                f32x4 (&acc)[4][4]) {
+            for (int ni = 0; ni < NT; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]),
+                    acc[mi][ni], 0, 0, 0);
+    } else {
+        // the 16 bytes are 4 consecutive k of one row; MFMA j of the group of four takes
+        // element j from both operands: k-slot g of MFMA j stands for k = 4g + j in A and B
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], b[ni][j],
-                                                                   acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < NT; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][j], b[ni][j],
+                                                                       acc[mi][ni], 0, 0, 0);
+    }
 }
 
 template <typename T>
@@ -95,8 +102,84 @@ __device__ __forceinline__ void store8(char *out, long elem_index, const float (
     }
 }
 
+// GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the
+// bf16 rounding of the result), written so that negative arguments do not cancel:
+//   gelu(x) = 0.5 x erfc(|x|/sqrt2) for x < 0,  0.5 x (2 - erfc(|x|/sqrt2)) otherwise.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(t, 1.061405429f, -1.453152027f);
+    poly = fmaf(t, poly, 1.421413741f);
+    poly = fmaf(t, poly, -0.284496736f);
+    poly = fmaf(t, poly, 0.254829592f);
+    poly *= t;
+    const float erfc_abs = poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    return 0.5f * x * (x < 0.f ? erfc_abs : 2.0f - erfc_abs);
+}
+
+// Epilogue arithmetic on 8 consecutive columns n..n+7 of row m; c = A.W^T (no bias yet).
 template <typename T, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ void epilogue8(const GemmParams &p, int m, int n, int section,
+                                          const f32x4 &c0, const f32x4 &c1, const float (&bias)[8]) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = c0[j] + bias[j]; v[4 + j] = c1[j] + bias[4 + j]; }
+    const long o = (long)m * p.ldo + n;
+    if constexpr (EPI == TC_EPI_BIAS) {
+        store8<T>(p.out, o, v);
+    } else if constexpr (EPI == TC_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = sizeof(T) == 2 ? gelu_fast(v[j]) : tc_gelu(v[j]);
+        store8<T>(p.out, o, v);
+    } else if constexpr (EPI == TC_EPI_BIAS_RESIDUAL) {
+        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(p.residual + o);
+        const f32x4 r1 = *reinterpret_cast<const f32x4 *>(p.residual + o + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = r0[j] + v[j]; v[4 + j] = r1[j] + v[4 + j]; }
+        store8<float>(p.out, o, v);
+    } else {  // TC_EPI_QKV_ROPE: section 0 = q, 1 = k, 2 = v (uniform per workgroup)
+        if (section == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= p.q_scale;
+        }
+        if (section < 2) {
+            const int pos = m % p.T;
+            const long t = (long)pos * (p.head_dim >> 1) + ((n % p.head_dim) >> 1);
+            const f32x4 cs = *reinterpret_cast<const f32x4 *>(p.rope_cos + t);
+            const f32x4 sn = *reinterpret_cast<const f32x4 *>(p.rope_sin + t);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x0 = v[2 * j], x1 = v[2 * j + 1];
+                v[2 * j] = x0 * cs[j] - x1 * sn[j];
+                v[2 * j + 1] = x1 * cs[j] + x0 * sn[j];
+            }
+        }
+        store8<T>(p.out, o, v);
+    }
+}
+
+__device__ __forceinline__ void load_bias8(const float *bias, int n, float (&b)[8]) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias + n);
+    const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bias + n + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { b[j] = b0[j]; b[4 + j] = b1[j]; }
+}
+
+// =============================================================================================
+// 128 x 128 tile, 4 waves
+// =============================================================================================
+namespace k128 {
+constexpr int BM = 128, BN = 128;
+constexpr int TILE_BYTES = 128 * 128;          // one operand k-tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
+constexpr int CST_LD = 68;                     // f32 per staged C row (64 + 4 pad)
+constexpr int CST_WAVE_BYTES = 64 * CST_LD * 4;
+constexpr int LDS_BYTES = (4 * CST_WAVE_BYTES > 2 * STAGE_BYTES) ? 4 * CST_WAVE_BYTES : 2 * STAGE_BYTES;
+}  // namespace k128
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
+    using namespace k128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -126,7 +209,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         for (int i = 0; i < 4; ++i) glds16(b_src[i] + koff, bbase + i * 1024);
     };
 
-    // ---- fragment read offsets (bytes inside an operand tile) ----
+    // ---- fragment read offsets (bytes inside a stage) ----
     const int wm = wid >> 1, wn = wid & 1;
     const int frow = lane & 15, fgrp = lane >> 4;
     int a_off[2], b_off[2];                     // per k-step; + mi*16 rows added as immediates
@@ -157,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
                 a[i] = *reinterpret_cast<const f32x4 *>(sbase + a_off[ks] + i * 16 * 128);
                 b[i] = *reinterpret_cast<const f32x4 *>(sbase + b_off[ks] + i * 16 * 128);
             }
-            mma_step<T>(a, b, acc);
+            mma_step<T, 4, 4>(a, b, acc);
         }
     }
 
@@ -176,95 +259,309 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     const int rsub = lane >> 3, cg = lane & 7;
     const int n = n0 + wn * 64 + cg * 8;         // first of this lane's 8 columns
     float bias[8];
-    {
-        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(p.bias + n);
-        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(p.bias + n + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { bias[j] = b0[j]; bias[4 + j] = b1[j]; }
-    }
-    int section = 0, pair0 = 0;                  // QKV: 0 = q, 1 = k, 2 = v (uniform per block)
-    if constexpr (EPI == TC_EPI_QKV_ROPE) {
-        section = n0 / p.E;
-        pair0 = (n % p.head_dim) >> 1;
-    }
+    load_bias8(p.bias, n, bias);
+    const int section = EPI == TC_EPI_QKV_ROPE ? n0 / p.E : 0;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int row = it * 8 + rsub;
         const int m = m0 + wm * 64 + row;
         const f32x4 c0 = *reinterpret_cast<const f32x4 *>(cst + row * CST_LD + cg * 8);
         const f32x4 c1 = *reinterpret_cast<const f32x4 *>(cst + row * CST_LD + cg * 8 + 4);
-        if (m >= p.M) continue;
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] = c0[j] + bias[j]; v[4 + j] = c1[j] + bias[4 + j]; }
-        const long o = (long)m * p.ldo + n;
-        if constexpr (EPI == TC_EPI_BIAS) {
-            store8<T>(p.out, o, v);
-        } else if constexpr (EPI == TC_EPI_BIAS_GELU) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = tc_gelu(v[j]);
-            store8<T>(p.out, o, v);
-        } else if constexpr (EPI == TC_EPI_BIAS_RESIDUAL) {
-            const f32x4 r0 = *reinterpret_cast<const f32x4 *>(p.residual + o);
-            const f32x4 r1 = *reinterpret_cast<const f32x4 *>(p.residual + o + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] = r0[j] + v[j]; v[4 + j] = r1[j] + v[4 + j]; }
-            store8<float>(p.out, o, v);
-        } else {  // TC_EPI_QKV_ROPE
-            if (section == 0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= p.q_scale;
-            }
-            if (section < 2) {
-                const int pos = m % p.T;
-                const long t = (long)pos * (p.head_dim >> 1) + pair0;
-                const f32x4 cs = *reinterpret_cast<const f32x4 *>(p.rope_cos + t);
-                const f32x4 sn = *reinterpret_cast<const f32x4 *>(p.rope_sin + t);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float x0 = v[2 * j], x1 = v[2 * j + 1];
-                    v[2 * j] = x0 * cs[j] - x1 * sn[j];
-                    v[2 * j + 1] = x1 * cs[j] + x0 * sn[j];
-                }
-            }
-            store8<T>(p.out, o, v);
-        }
+        if (m < p.M) epilogue8<T, EPI>(p, m, n, section, c0, c1, bias);
     }
 }
 
+// =============================================================================================
+// 256 x 256 tile, 8 waves, persistent
+// =============================================================================================
+namespace k256 {
+constexpr int BM = 256, BN = 256;
+constexpr int TILE_BYTES = 256 * 128;          // one operand k-tile (32 KiB)
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B (64 KiB)
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;     // 128 KiB
+}  // namespace k256
+
+// The MFMA operands are swapped here (A operand = W rows, B operand = activation rows), so an
+// accumulator tile is D[n][m]: the lane holds 4 CONSECUTIVE output columns n of one output row m.
+// The epilogue then needs no LDS: bias / GELU / rotary pairs / residual act on the lane's own 4
+// columns and every store is 8 bytes (bf16) or 16 bytes (f32), 16 rows x 32..64 contiguous bytes
+// per wave instruction.  For the bf16 residual epilogue the f32 residual tile is loaded straight
+// into the accumulators before the k-loop (its latency hides behind the whole loop).
 template <typename T, int EPI>
-int launch(const GemmParams &p, hipStream_t stream) {
-    static bool attr_set = false;   // benign race: the attribute call is idempotent
-    auto kern = gemm_kernel<T, EPI>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           GEMM_LDS_BYTES);
-        if (e != hipSuccess) {
-            tc_set_error("tc_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return TC_ELAUNCH;
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
+    using namespace k256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wid >> 2, wn = wid & 3;                 // 2 x 4 waves, 128 (m) x 64 (n) each
+    const int frow = lane & 15, fgrp = lane >> 4;
+    constexpr bool kPreloadResidual = EPI == TC_EPI_BIAS_RESIDUAL && sizeof(T) == 2;
+
+    // ---- this workgroup's tiles: the 8 workgroups-per-XCD classes (id & 7) own contiguous
+    // tile ranges; inside a class, workgroup j takes tiles j, j + per_class, ... so that the
+    // workgroups that run side by side on one XCD work on neighbouring tiles (shared A row
+    // panels and W column panels hit that XCD's L2).
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int cls = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int per_class = (gridDim.x + 7 - cls) >> 3;      // workgroups in this class
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int first = cls < r ? cls * (q + 1) : r * (q + 1) + (cls - r) * q;
+    const int count = q + (cls < r ? 1 : 0);
+    const int my_count = count > j ? (count - j + per_class - 1) / per_class : 0;
+
+    // tile index -> (row panel, column panel): groups of gm row panels, walked m-fastest
+    auto tile_coords = [&](int tile, int &tm, int &tn) {
+        const int per_group = p.gm * p.tiles_n;
+        const int grp = tile / per_group, loc = tile - grp * per_group;
+        const int rows_here = min(p.gm, p.tiles_m - grp * p.gm);
+        tn = loc / rows_here;
+        tm = grp * p.gm + (loc - tn * rows_here);
+    };
+
+    // ---- staging: per stage and wave 4 pieces of A and 4 of W (8 rows x 128 B each) ----
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const char *a_src[4], *b_src[4];
+    auto set_load_tile = [&](int local) {
+        int tm, tn;
+        tile_coords(first + j + local * per_class, tm, tn);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wid * 4 + i) * 8 + srow;
+            int gm = tm * BM + row;
+            gm = gm < p.M ? gm : p.M - 1;
+            a_src[i] = p.A + (long)gm * p.lda_bytes + schunk * 16;
+            b_src[i] = p.W + (long)(tn * BN + row) * p.ldw_bytes + schunk * 16;
         }
-        attr_set = true;
+    };
+    auto stage = [&](int buf, int kt) {
+        char *abase = smem + buf * STAGE_BYTES + wid * 4 * 1024;
+        char *bbase = abase + TILE_BYTES;
+        const long koff = (long)kt * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(a_src[i] + koff, abase + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(b_src[i] + koff, bbase + i * 1024);
+    };
+
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ((ks * 4 + fgrp) ^ (frow & 7)) << 4;
+        a_off[ks] = (wm * 128 + frow) * 128 + c;
+        b_off[ks] = TILE_BYTES + (wn * 64 + frow) * 128 + c;
     }
-    const int grid = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), GEMM_LDS_BYTES, stream, p);
+
+    if (my_count == 0) return;
+    int ld_tile = 0, ld_k = 0;                  // load cursor, one k-tile ahead of the math
+    set_load_tile(0);
+    stage(0, 0);
+    ld_k = 1;
+    if (ld_k == p.nk) { ld_k = 0; ld_tile = 1; if (ld_tile < my_count) set_load_tile(ld_tile); }
+
+#ifdef TC_GEMM_STAMPS
+    unsigned long long c_wait = 0, c_issue = 0, c_math = 0, c_epi = 0;
+#endif
+    int g = 0;                                   // running k-tile count = LDS stage parity
+    for (int t = 0; t < my_count; ++t) {
+        int tm, tn;
+        tile_coords(first + j + t * per_class, tm, tn);
+        const int mrow0 = tm * BM + wm * 128 + frow;         // + mi*16
+        const int ncol0 = tn * BN + wn * 64 + fgrp * 4;      // + ni*16
+
+        f32x4 acc[4][8];                                      // [ni][mi], D[n][m]
+        if constexpr (kPreloadResidual) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int m = mrow0 + mi * 16;
+                const float *rp = p.residual + (long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = *reinterpret_cast<const f32x4 *>(rp + ni * 16);
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+        for (int kt = 0; kt < p.nk; ++kt, ++g) {
+            TC_STAMP(s0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                     // k-tile g landed; the other stage is free
+            TC_STAMP(s1);
+            if (ld_tile < my_count) {
+                stage((g + 1) & 1, ld_k);
+                if (++ld_k == p.nk) { ld_k = 0; if (++ld_tile < my_count) set_load_tile(ld_tile); }
+            }
+            TC_STAMP(s2);
+            const char *sbase = smem + (g & 1) * STAGE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f32x4 xa[8], wb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    wb[i] = *reinterpret_cast<const f32x4 *>(sbase + b_off[ks] + i * 16 * 128);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    xa[i] = *reinterpret_cast<const f32x4 *>(sbase + a_off[ks] + i * 16 * 128);
+                mma_step<T, 4, 8>(wb, xa, acc);
+            }
+#ifdef TC_GEMM_STAMPS
+            asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][7]));
+            TC_STAMP(s3);
+            c_wait += s1 - s0; c_issue += s2 - s1; c_math += s3 - s2;
+#endif
+        }
+        TC_STAMP(e0);
+
+        // ---- epilogue of tile t (the next tile's first k-tile is already in flight) ----
+        f32x4 bias[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bias[ni] = *reinterpret_cast<const f32x4 *>(p.bias + ncol0 + ni * 16);
+        const int section = EPI == TC_EPI_QKV_ROPE ? (tn * BN) / p.E : 0;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = mrow0 + mi * 16;
+            const bool ok = m < p.M;
+            const long orow = (long)(ok ? m : 0) * p.ldo + ncol0;
+            f32x4 cs[4], sn[4];
+            if constexpr (EPI == TC_EPI_QKV_ROPE) {
+                if (section < 2) {
+                    // this lane's 4 columns of n-tile ni are rotary pairs ni*8 + fgrp*2 + {0,1}
+                    const float *ct = p.rope_cos + (long)(m % p.T) * (p.head_dim >> 1) + fgrp * 2;
+                    const float *st = p.rope_sin + (long)(m % p.T) * (p.head_dim >> 1) + fgrp * 2;
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const int pi = ((wn * 64 + ni * 16) % p.head_dim) >> 1;
+                        cs[ni][0] = ct[pi]; cs[ni][1] = ct[pi + 1];
+                        sn[ni][0] = st[pi]; sn[ni][1] = st[pi + 1];
+                    }
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 v = acc[ni][mi] + bias[ni];
+                if constexpr (EPI == TC_EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = sizeof(T) == 2 ? gelu_fast(v[e]) : tc_gelu(v[e]);
+                } else if constexpr (EPI == TC_EPI_BIAS_RESIDUAL) {
+                    if constexpr (!kPreloadResidual) {
+                        if (ok) v = *reinterpret_cast<const f32x4 *>(p.residual + orow + ni * 16) + v;
+                    }
+                } else if constexpr (EPI == TC_EPI_QKV_ROPE) {
+                    if (section == 0) v *= p.q_scale;
+                    if (section < 2) {
+                        const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+                        v[0] = x0 * cs[ni][0] - x1 * sn[ni][0];
+                        v[1] = x1 * cs[ni][0] + x0 * sn[ni][0];
+                        v[2] = x2 * cs[ni][1] - x3 * sn[ni][1];
+                        v[3] = x3 * cs[ni][1] + x2 * sn[ni][1];
+                    }
+                }
+                if (ok) {
+                    if constexpr (EPI == TC_EPI_BIAS_RESIDUAL || sizeof(T) == 4) {
+                        *reinterpret_cast<f32x4 *>(p.out + (orow + ni * 16) * 4) = v;
+                    } else {
+                        u32x2 w;
+                        w[0] = tc_pack_bf16(v[0], v[1]);
+                        w[1] = tc_pack_bf16(v[2], v[3]);
+                        *reinterpret_cast<u32x2 *>(p.out + (orow + ni * 16) * 2) = w;
+                    }
+                }
+            }
+        }
+#ifdef TC_GEMM_STAMPS
+        TC_STAMP(e1);
+        c_epi += e1 - e0;
+#endif
+    }
+#ifdef TC_GEMM_STAMPS
+    if (p.stamps && threadIdx.x == 0) {
+        p.stamps[blockIdx.x * 4 + 0] = c_wait; p.stamps[blockIdx.x * 4 + 1] = c_issue;
+        p.stamps[blockIdx.x * 4 + 2] = c_math; p.stamps[blockIdx.x * 4 + 3] = c_epi;
+    }
+#endif
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+int g_num_cus = 0;
+#ifdef TC_GEMM_STAMPS
+unsigned long long *g_stamps = nullptr;
+#endif
+
+template <typename T, int EPI>
+int launch(const GemmParams &p0, bool big, hipStream_t stream) {
+    GemmParams p = p0;
+    if (big) {
+        static bool attr_set = false;   // benign race: the attribute call is idempotent
+        auto kern = gemm256_kernel<T, EPI>;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               k256::LDS_BYTES);
+            if (e != hipSuccess) {
+                tc_set_error("tc_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                return TC_ELAUNCH;
+            }
+            attr_set = true;
+        }
+        p.tiles_m = (p.M + k256::BM - 1) / k256::BM;
+        p.tiles_n = p.N / k256::BN;
+        const int ntiles = p.tiles_m * p.tiles_n;
+        int grid = ntiles < g_num_cus ? ntiles : g_num_cus;
+#ifdef TC_GEMM_STAMPS
+        { const char *e = getenv("TC_GEMM_GRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
+#endif
+        {
+            static int gm = 0;
+            if (gm == 0) { const char *e = getenv("TC_GEMM_GM"); gm = e ? atoi(e) : 1; if (gm < 1) gm = 1; }
+            p.gm = gm;
+        }
+#ifdef TC_GEMM_STAMPS
+        p.stamps = g_stamps;
+#endif
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), k256::LDS_BYTES, stream, p);
+    } else {
+        static bool attr_set = false;
+        auto kern = gemm128_kernel<T, EPI>;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               k128::LDS_BYTES);
+            if (e != hipSuccess) {
+                tc_set_error("tc_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                return TC_ELAUNCH;
+            }
+            attr_set = true;
+        }
+        p.tiles_m = (p.M + k128::BM - 1) / k128::BM;
+        p.tiles_n = p.N / k128::BN;
+        hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), k128::LDS_BYTES, stream, p);
+    }
     TC_CHECK_LAUNCH("tc_gemm");
     return TC_OK;
 }
 
 template <typename T>
-int dispatch(int epilogue, const GemmParams &p, hipStream_t stream) {
+int dispatch(int epilogue, const GemmParams &p, bool big, hipStream_t stream) {
     switch (epilogue) {
-        case TC_EPI_BIAS: return launch<T, TC_EPI_BIAS>(p, stream);
-        case TC_EPI_BIAS_GELU: return launch<T, TC_EPI_BIAS_GELU>(p, stream);
-        case TC_EPI_BIAS_RESIDUAL: return launch<T, TC_EPI_BIAS_RESIDUAL>(p, stream);
-        case TC_EPI_QKV_ROPE: return launch<T, TC_EPI_QKV_ROPE>(p, stream);
+        case TC_EPI_BIAS: return launch<T, TC_EPI_BIAS>(p, big, stream);
+        case TC_EPI_BIAS_GELU: return launch<T, TC_EPI_BIAS_GELU>(p, big, stream);
+        case TC_EPI_BIAS_RESIDUAL: return launch<T, TC_EPI_BIAS_RESIDUAL>(p, big, stream);
+        case TC_EPI_QKV_ROPE: return launch<T, TC_EPI_QKV_ROPE>(p, big, stream);
     }
     tc_set_error("tc_gemm: unknown epilogue %d", epilogue);
     return TC_EINVAL;
 }
 
 }  // namespace
+
+#ifdef TC_GEMM_STAMPS
+extern "C" void tc_debug_set_stamp_buffer(void *p) { g_stamps = static_cast<unsigned long long *>(p); }
+#endif
 
 extern "C" int tc_gemm(int dtype, int epilogue, const void *A, int lda, const void *W,
                        const float *bias, const float *residual, void *out, int ldo, int M, int N,
@@ -275,7 +572,7 @@ extern "C" int tc_gemm(int dtype, int epilogue, const void *A, int lda, const vo
     const int kt = 128 / esz;
     TC_REQUIRE(A && W && bias && out, "tc_gemm: null operand");
     TC_REQUIRE(M > 0 && N > 0 && K > 0, "tc_gemm: empty problem M=%d N=%d K=%d", M, N, K);
-    TC_REQUIRE(N % BN == 0, "tc_gemm: N=%d must be a multiple of %d", N, BN);
+    TC_REQUIRE(N % 128 == 0, "tc_gemm: N=%d must be a multiple of 128", N);
     TC_REQUIRE(K % kt == 0, "tc_gemm: K=%d must be a multiple of %d", K, kt);
     TC_REQUIRE(lda >= K && ldo >= N, "tc_gemm: leading dimensions lda=%d ldo=%d too small", lda, ldo);
     TC_REQUIRE((lda * esz) % 16 == 0 && ldo % 8 == 0, "tc_gemm: leading dimensions must keep rows 16-byte aligned");
@@ -293,8 +590,6 @@ extern "C" int tc_gemm(int dtype, int epilogue, const void *A, int lda, const vo
     p.ldw_bytes = (long)K * esz;
     p.ldo = ldo;
     p.M = M; p.N = N; p.K = K;
-    p.tiles_m = (M + BM - 1) / BM;
-    p.tiles_n = N / BN;
     p.nk = K / kt;
     p.T = T; p.head_dim = head_dim; p.E = N / 3;
     p.q_scale = q_scale;
@@ -302,13 +597,31 @@ extern "C" int tc_gemm(int dtype, int epilogue, const void *A, int lda, const vo
         TC_REQUIRE(residual && tc_aligned16(residual), "tc_gemm: residual epilogue needs an aligned residual");
     }
     if (epilogue == TC_EPI_QKV_ROPE) {
-        TC_REQUIRE(N % 3 == 0 && (N / 3) % BN == 0, "tc_gemm: qkv epilogue needs N = 3E with E %% %d == 0", BN);
+        TC_REQUIRE(N % 3 == 0 && (N / 3) % 128 == 0, "tc_gemm: qkv epilogue needs N = 3E with E %% 128 == 0");
         TC_REQUIRE(rope_cos && rope_sin && T > 0, "tc_gemm: qkv epilogue needs rope tables and T");
         TC_REQUIRE(head_dim > 0 && head_dim % 8 == 0 && (N / 3) % head_dim == 0,
                    "tc_gemm: head_dim=%d must be a multiple of 8 dividing E", head_dim);
         TC_REQUIRE(tc_aligned16(rope_cos) && tc_aligned16(rope_sin), "tc_gemm: rope tables must be 16-byte aligned");
     }
+    if (g_num_cus == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+            tc_set_error("tc_gemm: cannot query the compute-unit count");
+            return TC_ELAUNCH;
+        }
+        g_num_cus = cus;
+    }
+    // the large tile needs N % 256 == 0 (and, for the fused q/k/v epilogue, E % 256 == 0 so that
+    // a tile never straddles two sections) and enough tiles to occupy every CU
+    bool big = N % 256 == 0 && (long)((M + 255) / 256) * (N / 256) >= g_num_cus;
+    if (epilogue == TC_EPI_QKV_ROPE && (N / 3) % 256 != 0) big = false;
+    {
+        static int force = -2;
+        if (force == -2) { const char *e = getenv("TC_GEMM_TILE"); force = e ? atoi(e) : -1; }
+        if (force == 128) big = false;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     TcProfScope prof(TC_PROF_GEMM, s, 2.0 * (double)M * (double)N * (double)K);
-    return dtype == TC_BF16 ? dispatch<__bf16>(epilogue, p, s) : dispatch<float>(epilogue, p, s);
+    return dtype == TC_BF16 ? dispatch<__bf16>(epilogue, p, big, s) : dispatch<float>(epilogue, p, big, s);
 }
