@@ -10,7 +10,11 @@ import torch
 from oracle import transcodon_ref as O
 from oracle.weights import seeded_state_dict, state_dict_spec
 
-torch.set_grad_enabled(False)
+
+@pytest.fixture(autouse=True)
+def _no_grad():
+    with torch.no_grad():
+        yield
 
 
 def test_state_dict_inventory(golden_dir):

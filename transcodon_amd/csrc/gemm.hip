@@ -117,6 +117,28 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return 0.5f * x * (x < 0.f ? erfc_abs : 2.0f - erfc_abs);
 }
 
+// Two values at a time: the polynomial and the scalings map onto packed f32 VALU ops.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 z = ax * 0.70710678118654752440f;
+    const f32x2 d = z * 0.3275911f + 1.0f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 poly = t * 1.061405429f + -1.453152027f;
+    poly = t * poly + 1.421413741f;
+    poly = t * poly + -0.284496736f;
+    poly = t * poly + 0.254829592f;
+    poly = poly * t;
+    const f32x2 a = z * z * -1.4426950408889634f;
+    const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    const f32x2 erfc_abs = poly * e;
+    const f32x2 hx = x * 0.5f;
+    f32x2 r;
+    r[0] = hx[0] * (x[0] < 0.f ? erfc_abs[0] : 2.0f - erfc_abs[0]);
+    r[1] = hx[1] * (x[1] < 0.f ? erfc_abs[1] : 2.0f - erfc_abs[1]);
+    return r;
+}
+
 // Epilogue arithmetic on 8 consecutive columns n..n+7 of row m; c = A.W^T (no bias yet).
 template <typename T, int EPI>
 __device__ __forceinline__ void epilogue8(const GemmParams &p, int m, int n, int section,
@@ -321,7 +343,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     // ---- staging: per stage and wave 4 pieces of A and 4 of W (8 rows x 128 B each) ----
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
-    const char *a_src[4], *b_src[4];
+    unsigned a_src[4], b_src[4];                // byte offsets (the host keeps both operands < 4 GiB)
     auto set_load_tile = [&](int local) {
         int tm, tn;
         tile_coords(first + j + local * per_class, tm, tn);
@@ -330,18 +352,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             const int row = (wid * 4 + i) * 8 + srow;
             int gm = tm * BM + row;
             gm = gm < p.M ? gm : p.M - 1;
-            a_src[i] = p.A + (long)gm * p.lda_bytes + schunk * 16;
-            b_src[i] = p.W + (long)(tn * BN + row) * p.ldw_bytes + schunk * 16;
+            a_src[i] = (unsigned)gm * (unsigned)p.lda_bytes + schunk * 16;
+            b_src[i] = (unsigned)(tn * BN + row) * (unsigned)p.ldw_bytes + schunk * 16;
         }
     };
     auto stage = [&](int buf, int kt) {
         char *abase = smem + buf * STAGE_BYTES + wid * 4 * 1024;
         char *bbase = abase + TILE_BYTES;
-        const long koff = (long)kt * 128;
+        const unsigned koff = (unsigned)kt * 128u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(a_src[i] + koff, abase + i * 1024);
+        for (int i = 0; i < 4; ++i) glds16(p.A + (a_src[i] + koff), abase + i * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(b_src[i] + koff, bbase + i * 1024);
+        for (int i = 0; i < 4; ++i) glds16(p.W + (b_src[i] + koff), bbase + i * 1024);
     };
 
     int a_off[2], b_off[2];
@@ -363,32 +385,48 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     unsigned long long c_wait = 0, c_issue = 0, c_math = 0, c_epi = 0;
 #endif
     int g = 0;                                   // running k-tile count = LDS stage parity
+    bool prev_full = false;                      // previous tile had no row tail (all stores issued)
     for (int t = 0; t < my_count; ++t) {
         int tm, tn;
         tile_coords(first + j + t * per_class, tm, tn);
         const int mrow0 = tm * BM + wm * 128 + frow;         // + mi*16
         const int ncol0 = tn * BN + wn * 64 + fgrp * 4;      // + ni*16
 
+        // accumulators start at bias (+ residual): no bias registers are held through the loop
         f32x4 acc[4][8];                                      // [ni][mi], D[n][m]
-        if constexpr (kPreloadResidual) {
+        {
+            f32x4 bias[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bias[ni] = *reinterpret_cast<const f32x4 *>(p.bias + ncol0 + ni * 16);
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
-                const int m = mrow0 + mi * 16;
-                const float *rp = p.residual + (long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0;
+                if constexpr (kPreloadResidual) {
+                    const int m = mrow0 + mi * 16;
+                    const float *rp = p.residual + (long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0;
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = *reinterpret_cast<const f32x4 *>(rp + ni * 16);
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[ni][mi] = *reinterpret_cast<const f32x4 *>(rp + ni * 16) + bias[ni];
+                } else {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = bias[ni];
+                }
             }
-        } else {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
         for (int kt = 0; kt < p.nk; ++kt, ++g) {
             TC_STAMP(s0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                     // k-tile g landed; the other stage is free
+            // k-tile g was issued one iteration ago.  Right after a full tile's epilogue the
+            // only younger operations are that epilogue's 32 stores and this tile's accumulator
+            // initialisation loads; leaving those in flight keeps the store drain off the
+            // critical path (the vector-memory counter retires in issue order).
+            if (kt == 0 && t > 0 && prev_full) {
+                if constexpr (kPreloadResidual) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();        // k-tile g landed; the other stage is free
+            asm volatile("" ::: "memory");
             TC_STAMP(s1);
             if (ld_tile < my_count) {
                 stage((g + 1) & 1, ld_k);
@@ -398,14 +436,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             const char *sbase = smem + (g & 1) * STAGE_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                f32x4 xa[8], wb[4];
+                f32x4 wb[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     wb[i] = *reinterpret_cast<const f32x4 *>(sbase + b_off[ks] + i * 16 * 128);
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    xa[i] = *reinterpret_cast<const f32x4 *>(sbase + a_off[ks] + i * 16 * 128);
-                mma_step<T, 4, 8>(wb, xa, acc);
+                for (int hm = 0; hm < 2; ++hm) {          // 4 row tiles at a time: 16 MFMAs
+                    f32x4 xa[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        xa[i] = *reinterpret_cast<const f32x4 *>(sbase + a_off[ks] + (hm * 4 + i) * 16 * 128);
+                    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                acc[ni][hm * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(bf16x8, wb[ni]), __builtin_bit_cast(bf16x8, xa[i]),
+                                    acc[ni][hm * 4 + i], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    acc[ni][hm * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                        wb[ni][jj], xa[i][jj], acc[ni][hm * 4 + i], 0, 0, 0);
+                    }
+                }
             }
 #ifdef TC_GEMM_STAMPS
             asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][7]));
@@ -416,50 +475,86 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         TC_STAMP(e0);
 
         // ---- epilogue of tile t (the next tile's first k-tile is already in flight) ----
-        f32x4 bias[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) bias[ni] = *reinterpret_cast<const f32x4 *>(p.bias + ncol0 + ni * 16);
+        // phase 1: arithmetic in place (its table loads are not queued behind any store);
+        // phase 2: all stores.
+        prev_full = (tm * BM + BM) <= p.M;
         const int section = EPI == TC_EPI_QKV_ROPE ? (tn * BN) / p.E : 0;
+        if constexpr (EPI == TC_EPI_BIAS_GELU) {
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = mrow0 + mi * 16;
-            const bool ok = m < p.M;
-            const long orow = (long)(ok ? m : 0) * p.ldo + ncol0;
-            f32x4 cs[4], sn[4];
-            if constexpr (EPI == TC_EPI_QKV_ROPE) {
-                if (section < 2) {
-                    // this lane's 4 columns of n-tile ni are rotary pairs ni*8 + fgrp*2 + {0,1}
-                    const float *ct = p.rope_cos + (long)(m % p.T) * (p.head_dim >> 1) + fgrp * 2;
-                    const float *st = p.rope_sin + (long)(m % p.T) * (p.head_dim >> 1) + fgrp * 2;
+            for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
-                        const int pi = ((wn * 64 + ni * 16) % p.head_dim) >> 1;
-                        cs[ni][0] = ct[pi]; cs[ni][1] = ct[pi + 1];
-                        sn[ni][0] = st[pi]; sn[ni][1] = st[pi + 1];
+                for (int mi = 0; mi < 8; ++mi) {
+                    f32x4 v = acc[ni][mi];
+                    if constexpr (sizeof(T) == 2) {
+                        const f32x2 lo = gelu_fast2(f32x2{v[0], v[1]}), hi = gelu_fast2(f32x2{v[2], v[3]});
+                        v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = tc_gelu(v[e]);
+                    }
+                    acc[ni][mi] = v;
+                }
+        } else if constexpr (EPI == TC_EPI_QKV_ROPE) {
+            if (section < 2) {
+                const float qs = section == 0 ? p.q_scale : 1.0f;
+                const int half = p.head_dim >> 1;
+                // this lane's 4 columns of n-tile ni are rotary pairs pi(ni) + fgrp*2 + {0,1}
+                const int tile_pos0 = (tm * BM) % p.T;
+                const bool recur = sizeof(T) == 2 && tile_pos0 + BM <= p.T;
+                // No sequence boundary inside the tile (recur): rows 16 apart differ by a fixed
+                // angle, so only the first row's cos/sin are gathered (a gather touches 16 table
+                // rows per load instruction, which is what makes it expensive) and the other seven
+                // follow by angle addition with the table's row 16; 7 steps keep f32 accuracy.
+                // One n-tile at a time keeps the live rotary state at 8 registers.
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int pi = (((wn * 64 + ni * 16) % p.head_dim) >> 1) + fgrp * 2;
+                    if (recur) {
+                        const long row = (long)(tile_pos0 + wm * 128 + frow) * half + pi;
+                        f32x2 c = *reinterpret_cast<const f32x2 *>(p.rope_cos + row);
+                        f32x2 sn = *reinterpret_cast<const f32x2 *>(p.rope_sin + row);
+                        const f32x2 c16 = *reinterpret_cast<const f32x2 *>(p.rope_cos + 16L * half + pi);
+                        const f32x2 s16 = *reinterpret_cast<const f32x2 *>(p.rope_sin + 16L * half + pi);
+#pragma unroll
+                        for (int mi = 0; mi < 8; ++mi) {
+                            const f32x4 v = acc[ni][mi] * qs;
+                            acc[ni][mi] = f32x4{v[0] * c[0] - v[1] * sn[0], v[1] * c[0] + v[0] * sn[0],
+                                                v[2] * c[1] - v[3] * sn[1], v[3] * c[1] + v[2] * sn[1]};
+                            const f32x2 cn = c * c16 - sn * s16;
+                            sn = sn * c16 + c * s16;
+                            c = cn;
+                        }
+                    } else {
+#pragma unroll
+                        for (int mi = 0; mi < 8; ++mi) {
+                            const long row = (long)((mrow0 + mi * 16) % p.T) * half + pi;
+                            const f32x2 c = *reinterpret_cast<const f32x2 *>(p.rope_cos + row);
+                            const f32x2 sn = *reinterpret_cast<const f32x2 *>(p.rope_sin + row);
+                            const f32x4 v = acc[ni][mi] * qs;
+                            acc[ni][mi] = f32x4{v[0] * c[0] - v[1] * sn[0], v[1] * c[0] + v[0] * sn[0],
+                                                v[2] * c[1] - v[3] * sn[1], v[3] * c[1] + v[2] * sn[1]};
+                        }
                     }
                 }
             }
+        } else if constexpr (EPI == TC_EPI_BIAS_RESIDUAL && !kPreloadResidual) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                f32x4 v = acc[ni][mi] + bias[ni];
-                if constexpr (EPI == TC_EPI_BIAS_GELU) {
+            for (int mi = 0; mi < 8; ++mi) {
+                const int m = mrow0 + mi * 16;
+                const float *rp = p.residual + (long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = sizeof(T) == 2 ? gelu_fast(v[e]) : tc_gelu(v[e]);
-                } else if constexpr (EPI == TC_EPI_BIAS_RESIDUAL) {
-                    if constexpr (!kPreloadResidual) {
-                        if (ok) v = *reinterpret_cast<const f32x4 *>(p.residual + orow + ni * 16) + v;
-                    }
-                } else if constexpr (EPI == TC_EPI_QKV_ROPE) {
-                    if (section == 0) v *= p.q_scale;
-                    if (section < 2) {
-                        const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
-                        v[0] = x0 * cs[ni][0] - x1 * sn[ni][0];
-                        v[1] = x1 * cs[ni][0] + x0 * sn[ni][0];
-                        v[2] = x2 * cs[ni][1] - x3 * sn[ni][1];
-                        v[3] = x3 * cs[ni][1] + x2 * sn[ni][1];
-                    }
-                }
-                if (ok) {
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[ni][mi] = *reinterpret_cast<const f32x4 *>(rp + ni * 16) + acc[ni][mi];
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = mrow0 + mi * 16;
+            if (m < p.M) {
+                const long orow = (long)m * p.ldo + ncol0;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const f32x4 v = acc[ni][mi];
                     if constexpr (EPI == TC_EPI_BIAS_RESIDUAL || sizeof(T) == 4) {
                         *reinterpret_cast<f32x4 *>(p.out + (orow + ni * 16) * 4) = v;
                     } else {
@@ -496,6 +591,7 @@ template <typename T, int EPI>
 int launch(const GemmParams &p0, bool big, hipStream_t stream) {
     GemmParams p = p0;
     if (big) {
+        if constexpr (sizeof(T) == 2) {
         static bool attr_set = false;   // benign race: the attribute call is idempotent
         auto kern = gemm256_kernel<T, EPI>;
         if (!attr_set) {
@@ -524,6 +620,7 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
         p.stamps = g_stamps;
 #endif
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), k256::LDS_BYTES, stream, p);
+        }
     } else {
         static bool attr_set = false;
         auto kern = gemm128_kernel<T, EPI>;
@@ -614,8 +711,10 @@ extern "C" int tc_gemm(int dtype, int epilogue, const void *A, int lda, const vo
     }
     // the large tile needs N % 256 == 0 (and, for the fused q/k/v epilogue, E % 256 == 0 so that
     // a tile never straddles two sections) and enough tiles to occupy every CU
-    bool big = N % 256 == 0 && (long)((M + 255) / 256) * (N / 256) >= g_num_cus;
+    bool big = N % 256 == 0 && (long)((M + 255) / 256) * (N / 256) >= g_num_cus &&
+               (long)M * lda * esz < (1L << 32) && (long)N * K * esz < (1L << 32);
     if (epilogue == TC_EPI_QKV_ROPE && (N / 3) % 256 != 0) big = false;
+    if (dtype != TC_BF16) big = false;   // the f32 path is MFMA-rate bound (1/16 of bf16): small tile is enough
     {
         static int force = -2;
         if (force == -2) { const char *e = getenv("TC_GEMM_TILE"); force = e ? atoi(e) : -1; }
