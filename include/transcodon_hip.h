@@ -46,6 +46,10 @@ extern "C" {
 #define TC_EPI_BIAS_GELU 1       /* out = gelu_erf(A W^T + b)                        */
 #define TC_EPI_BIAS_RESIDUAL 2   /* out_f32 = residual_f32 + A W^T + b               */
 #define TC_EPI_QKV_ROPE 3        /* fused q/k/v projection, q scale, RoPE on q and k */
+/* training-only epilogues (tc_gemm_train) */
+#define TC_EPI_PLAIN_F32 4       /* out_f32 = A W^T (+ b if given); split-K partial slabs       */
+#define TC_EPI_BIAS_GELU_SAVE 5  /* out2 = A W^T + b (kept for backward), out = gelu_erf(out2)  */
+#define TC_EPI_DGELU 6           /* out = (A W^T) * gelu'(aux)   (gradient through the GELU)    */
 
 int tc_version(void);
 const char *tc_last_error(void);
@@ -93,6 +97,20 @@ int tc_layernorm_fwd(const float *x, const float *gamma, const float *beta, floa
 int tc_gemm(int dtype, int epilogue, const void *A, int lda, const void *W, const float *bias,
             const float *residual, void *out, int ldo, int M, int N, int K, float q_scale,
             const float *rope_cos, const float *rope_sin, int T, int head_dim, void *stream);
+
+/*
+ * GEMM variants needed by the training step (pretraining.py:94-134 forward + autograd backward):
+ *   TC_EPI_BIAS_GELU_SAVE  forward fc1: also keeps the pre-activation (out2, element type dtype);
+ *   TC_EPI_DGELU           data gradient through fc1's GELU: aux = saved pre-activation [M,N];
+ *   TC_EPI_PLAIN_F32       data / weight gradients with f32 output.  With splits > 1 the k range
+ *                          is cut into `splits` parts and part s writes its partial product to
+ *                          out + s*M*ldo (f32); tc_reduce_slabs adds the parts up.
+ * Same shape rules as tc_gemm; weight gradients use it on transposed operands
+ * (dW[N,K] = dY^T[N,M] . X^T[K,M]^T with the token dimension M as the reduction).
+ */
+int tc_gemm_train(int dtype, int epilogue, const void *A, int lda, const void *W, const float *bias,
+                  const void *aux, void *out, void *out2, int ldo, int M, int N, int K, int splits,
+                  void *stream);
 
 /*
  * Key-validity bit masks for the attention kernel: bit j of words[b*nw + w] is 1
@@ -158,6 +176,70 @@ int tc_codon_decode(const float *logits, int ldl, const uint8_t *aa, const int32
 int tc_ce_loss_fwd_bwd(const float *logits, const int32_t *labels, float *loss_sum,
                        int32_t *count, float *dlogits, float grad_scale, int M, int V,
                        void *stream);
+
+/*
+ * Mean of the hidden states of each sequence over a row range (embedding extraction):
+ *   pooled[b, :] = mean_{t in [start[b], start[b]+len[b])} rep[b*T + t, :]
+ * Replaces the `repr_.mean(axis=1)` pooling of transcodon/infer_embedding.py:145 for
+ * right-padded batches (only real, non-special positions are averaged).
+ *   rep f32 [B*T,E]; start,len int32 [B]; pooled f32 [B,E]; len[b] == 0 gives a zero row.
+ */
+int tc_mean_pool(const float *rep, const int32_t *start, const int32_t *len, float *pooled, int B,
+                 int T, int E, void *stream);
+
+/* ---- backward-pass kernels of the training step (pretraining.py:94-134 + autograd) -- */
+
+/*
+ * out_t[n, m] = in[m, n] with element-type conversion (f32->f32, f32->bf16, bf16->bf16).
+ * out_t has leading dimension ldt >= M; columns [M, ldt) are zero-filled, so the token
+ * dimension can be the (padded) reduction dimension of a weight-gradient GEMM.
+ * out_rowmajor (optional): converted row-major copy [M, ld_rm].  colsum (optional, f32 [N],
+ * ACCUMULATED): column sums of `in`, i.e. the bias gradient of a Linear layer.
+ */
+int tc_transpose_cast(int in_dtype, int out_dtype, const void *in, int ld_in, void *out_t, int ldt,
+                      void *out_rowmajor, int ld_rm, float *colsum, int M, int N, void *stream);
+
+/* out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s*n + i]: combines split-K partial products. */
+int tc_reduce_slabs(const float *slabs, float *out, int S, long n, int accumulate, void *stream);
+
+/*
+ * Backward of torch.nn.LayerNorm(E, eps): given the layer INPUT x (f32 or bf16, leading dimension
+ * ldx), gamma and dy f32 [M,E]:  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma,
+ * written to or (accumulate != 0) added to dx f32 [M,E]; dgamma += sum_m dy * xhat,
+ * dbeta += sum_m dy (both ACCUMULATED).
+ */
+int tc_layernorm_bwd(int x_dtype, const void *x, int ldx, const float *gamma, const float *dy, float *dx,
+                     int accumulate, float *dgamma, float *dbeta, int M, int E, float eps, void *stream);
+
+/* out = dy * gelu'(u), elementwise over n values (exact erf form); u and out have type dtype. */
+int tc_dgelu(int dtype, const float *dy, const void *u, void *out, long n, void *stream);
+
+/*
+ * Backward of tc_head_logits_fwd up to (not including) its LayerNorm: with ln = LN(g),
+ *   d_ln[m,:] = sum_v dlogits[m,v] W[v,:]   (f32 [M,E], overwritten)
+ *   dW[v,:]  += sum_m dlogits[m,v] ln[m,:]  (f32 [V,E], ACCUMULATED; the tied LM projection
+ *                                            accumulates into the embed_tokens gradient)
+ *   dbias[v] += sum_m dlogits[m,v]
+ * Follow with tc_layernorm_bwd(x = g) to get d_g.  V must be 3 or 10, E <= 768.
+ */
+int tc_head_logits_bwd(int dtype, const void *g, int ldg, int col0, const float *gamma, const float *beta,
+                       const float *W, const float *dlogits, float *d_ln, float *dW, float *dbias, int M,
+                       int E, int V, float eps, void *stream);
+
+/*
+ * Backward of tc_embed_fwd: d_tok_table[tokens[b,t]] += dx[b*T+t] and
+ * d_species_table[species[b]] += sum_t dx[b*T+t], over non-pad positions (both ACCUMULATED).
+ */
+int tc_embed_bwd(const int32_t *tokens, const int32_t *species, const float *dx, float *d_tok_table,
+                 float *d_species_table, int B, int T, int E, int vocab, int n_species, int pad_idx,
+                 void *stream);
+
+/*
+ * Backward of the rotary rotation and the q scale, in place on the q ([0,E)) and k ([E,2E))
+ * column sections of d_qkv [M, ld]: (d0, d1) <- (d0 c + d1 s, d1 c - d0 s) * (q ? q_scale : 1).
+ */
+int tc_rope_bwd(int dtype, void *dqkv, int ld, const float *rope_cos, const float *rope_sin, int M, int T,
+                int E, int head_dim, float q_scale, void *stream);
 
 /* ---- whole-encoder convenience (one call per forward) ---------------------------- */
 

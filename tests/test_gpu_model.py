@@ -240,3 +240,19 @@ def test_synthetic_batch_oracle_vs_hip_bf16(full_sd, full_bf16):
     _check(out["logits"].cpu().numpy(), ref["logits"].numpy(), keep, torch.bfloat16)
     d = np.abs(out["representations"][12].cpu().numpy() - ref["representations"][12].numpy())[keep]
     assert float(d.max()) < 0.15
+
+
+def test_embedding_extraction_varlen(full_sd, full_f32):
+    """cfg5 in miniature: variable-length CDS batch, padded + key-masked; mean-pooled final
+    states against the oracle run one sequence at a time (as infer_embedding.py does)."""
+    rng = np.random.default_rng(1237)
+    seqs = ["".join(rng.choice(list("ACGT"), size=3 * int(n))) for n in (30, 77, 31, 120, 64)]
+    orgs = [int(x) for x in rng.integers(0, 1438, len(seqs))]
+    got = ta.extract_embeddings(full_f32, seqs, orgs, max_batch_tokens=400)
+    assert got.shape == (len(seqs), 768)
+    for i, s in enumerate(seqs):
+        toks = O.batch_tokens([O.encode(["<cls>"] + list(s.replace("T", "U")) + ["<eos>"])])
+        ref = O.forward(full_sd, O.FULL, toks, torch.tensor([orgs[i]]))["representations"][12][0, 1:-1].mean(0)
+        np.testing.assert_allclose(got[i].numpy(), ref.numpy(), atol=2e-4)
+    full = ta.extract_embeddings(full_f32, seqs[:2], orgs[:2], pooled=False)
+    assert [t.shape for t in full] == [(90, 768), (231, 768)]

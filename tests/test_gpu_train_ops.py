@@ -1,0 +1,170 @@
+"""Backward-pass kernels against torch autograd on the CPU (fp32 reference)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import transcodon_ref as O
+from transcodon_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M", [192, 1000, 40000])
+def test_linear_backward_via_gemm(dtype, M):
+    """dX = dY W and dW = dY^T X (split-K over the token dimension), db = colsum(dY)."""
+    N, K = 384, 256
+    x, w, dy = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.05), _rand(M, N, seed=3)
+    if dtype == torch.bfloat16:
+        x, w, dy = _bf(x), _bf(w), _bf(dy)
+    tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    xd, wd, dyd = x.to(DEV, dtype), w.to(DEV, dtype), dy.to(DEV, dtype)
+    # data gradient: A = dY [M,N], "W" = W^T [K,N]
+    wt, _, _ = ops.transpose_cast(wd, dtype, pad_to=64)
+    assert wt.shape == (K, N)
+    dx = ops.gemm_train(dyd, wt, _lib.EPI_PLAIN_F32)
+    np.testing.assert_allclose(dx.cpu().numpy(), (dy @ w).numpy(), **tol)
+    # weight gradient: dW[N,K] = dY^T[N,M] . (X^T[K,M])^T, 4-way split over the tokens
+    dyt, _, db = ops.transpose_cast(dyd, dtype, want_colsum=True)
+    xt, _, _ = ops.transpose_cast(xd, dtype)
+    assert dyt.shape[1] % 64 == 0 and float(dyt[:, M:].float().abs().sum()) == 0.0
+    slabs = ops.gemm_train(dyt, xt, _lib.EPI_PLAIN_F32, splits=4)
+    dw = ops.reduce_slabs(slabs)
+    ref = dy.t() @ x
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(dw.cpu().numpy() / scale, ref.numpy() / scale, rtol=0, atol=3e-3 if dtype == torch.bfloat16 else 1e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), dy.sum(0).numpy(), rtol=1e-4, atol=1e-3)
+    # accumulate into an existing gradient
+    acc = torch.ones_like(dw)
+    ops.reduce_slabs(slabs, out=acc, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), dw.cpu().numpy() + 1.0, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gelu_save_and_dgelu_epilogues(dtype):
+    M, N, K = 33000, 512, 256       # large enough for the persistent large-tile kernel in bf16
+    x, w, b, dy = _rand(M, K, seed=4), _rand(N, K, seed=5, scale=0.08), _rand(N, seed=6), _rand(M, N, seed=7)
+    if dtype == torch.bfloat16:
+        x, w, dy = _bf(x), _bf(w), _bf(dy)
+    tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    xd, wd = x.to(DEV, dtype), w.to(DEV, dtype)
+    y, pre = ops.gemm_train(xd, wd, _lib.EPI_BIAS_GELU_SAVE, bias=b.to(DEV))
+    u = x @ w.t() + b
+    np.testing.assert_allclose(pre.float().cpu().numpy(), u.numpy(), **tol)
+    np.testing.assert_allclose(y.float().cpu().numpy(), O.gelu(u).numpy(), **tol)
+    # gradient through gelu fused in the data-gradient GEMM: d_u = (dY_next W2) * gelu'(u)
+    w2 = _rand(K, N, seed=8, scale=0.08)          # next layer weight [out=K, in=N]
+    dz = _rand(M, K, seed=9)
+    if dtype == torch.bfloat16:
+        w2, dz = _bf(w2), _bf(dz)
+    w2t, _, _ = ops.transpose_cast(w2.to(DEV, dtype), dtype)     # [N, K]
+    du = ops.gemm_train(dz.to(DEV, dtype), w2t, _lib.EPI_DGELU, aux=pre)
+    pre_f = pre.float().cpu()
+    with torch.enable_grad():
+        uu = pre_f.clone().requires_grad_(True)
+        (O.gelu(uu) * (dz @ w2)).sum().backward()
+    np.testing.assert_allclose(du.float().cpu().numpy(), uu.grad.numpy(), **tol)
+    # standalone elementwise form
+    du2 = ops.dgelu((dz @ w2).to(DEV), pre)
+    np.testing.assert_allclose(du2.float().cpu().numpy(), uu.grad.numpy(), **tol)
+
+
+@pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("E", [128, 768])
+def test_layernorm_backward(xdtype, E):
+    M = 777
+    x, g, b, dy = _rand(M, E, seed=10, scale=2.0) + 0.3, _rand(E, seed=11) + 1.0, _rand(E, seed=12), _rand(M, E, seed=13)
+    if xdtype == torch.bfloat16:
+        x = _bf(x)
+    with torch.enable_grad():
+        xx, gg, bb = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        torch.nn.functional.layer_norm(xx, (E,), gg, bb, 1e-5).backward(dy)
+    dgam = torch.zeros(E, device=DEV)
+    dbet = torch.zeros(E, device=DEV)
+    carry = _rand(M, E, seed=14)
+    dx = carry.to(DEV).clone()
+    ops.layernorm_bwd(x.to(DEV, xdtype), g.to(DEV), dy.to(DEV), dgam, dbet, dx=dx, accumulate=True)
+    np.testing.assert_allclose(dx.cpu().numpy(), (carry + xx.grad).numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dgam.cpu().numpy(), gg.grad.numpy(), rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(dbet.cpu().numpy(), bb.grad.numpy(), rtol=1e-3, atol=2e-3)
+    dx2 = ops.layernorm_bwd(x.to(DEV, xdtype), g.to(DEV), dy.to(DEV), dgam, dbet)
+    np.testing.assert_allclose(dx2.cpu().numpy(), xx.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("E,V", [(768, 10), (768, 3), (128, 10)])
+def test_head_backward(dtype, E, V):
+    M = 333
+    gbuf = _rand(M, 2 * E, seed=15)
+    if dtype == torch.bfloat16:
+        gbuf = _bf(gbuf)
+    gam, bet, W, dl = _rand(E, seed=16) + 1, _rand(E, seed=17), _rand(V, E, seed=18, scale=0.1), _rand(M, V, seed=19)
+    col0 = E
+    with torch.enable_grad():
+        gg = gbuf[:, col0:].clone().requires_grad_(True)
+        ww, ga, be = W.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+        ln = torch.nn.functional.layer_norm(gg, (E,), ga, be, 1e-5)
+        ln.retain_grad()
+        (ln @ ww.t()).backward(dl)
+    dW = torch.zeros(V, E, device=DEV)
+    db = torch.zeros(V, device=DEV)
+    d_ln = ops.head_logits_bwd(gbuf.to(DEV, dtype), col0, E, gam.to(DEV), bet.to(DEV), W.to(DEV), dl.to(DEV), dW, db)
+    np.testing.assert_allclose(d_ln.cpu().numpy(), ln.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dW.cpu().numpy(), ww.grad.numpy(), rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), dl.sum(0).numpy(), rtol=1e-4, atol=1e-3)
+    # chain with the LayerNorm backward on the strided view of g
+    dgam, dbet = torch.zeros(E, device=DEV), torch.zeros(E, device=DEV)
+    gview = gbuf.to(DEV, dtype)[:, col0:]
+    dg = ops.layernorm_bwd(gview, gam.to(DEV), d_ln, dgam, dbet)
+    np.testing.assert_allclose(dg.cpu().numpy(), gg.grad.numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(dgam.cpu().numpy(), ga.grad.numpy(), rtol=1e-3, atol=2e-3)
+
+
+def test_embedding_backward():
+    B, T, E, V, S = 5, 37, 128, 10, 16
+    rng = np.random.default_rng(0)
+    tok = torch.from_numpy(rng.integers(0, V, (B, T)))
+    tok[:, -5:] = 1
+    sp = torch.tensor([3, 3, 0, 15, 7])
+    dx = _rand(B * T, E, seed=20)
+    d_tok, d_sp = torch.zeros(V, E, device=DEV), torch.zeros(S, E, device=DEV)
+    ops.embed_bwd(tok.to(DEV), sp.to(DEV), dx.to(DEV), d_tok, d_sp)
+    keep = (tok != 1).reshape(-1)
+    ref_tok = torch.zeros(V, E).index_add_(0, tok.reshape(-1)[keep], dx[keep])
+    ref_sp = torch.zeros(S, E).index_add_(0, sp.repeat_interleave(T)[keep], dx[keep])
+    np.testing.assert_allclose(d_tok.cpu().numpy(), ref_tok.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(d_sp.cpu().numpy(), ref_sp.numpy(), rtol=1e-5, atol=1e-5)
+    assert float(d_tok[1].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_rope_backward(dtype):
+    B, T, H = 2, 29, 2
+    E, D, M = H * 64, 64, B * T
+    freqs = O.rope_freqs(D)
+    ang = torch.arange(T, dtype=torch.float32)[:, None] * freqs[None, :]
+    dqkv = _rand(M, 3 * E, seed=21)
+    if dtype == torch.bfloat16:
+        dqkv = _bf(dqkv)
+    with torch.enable_grad():
+        pre = _rand(M, 3 * E, seed=22).requires_grad_(True)
+
+        def rot(t):
+            t = t.view(B, T, H, D).permute(0, 2, 1, 3)
+            return O.rope_rotate(t, freqs).permute(0, 2, 1, 3).reshape(M, E)
+
+        out = torch.cat([rot(pre[:, :E] * 0.125), rot(pre[:, E:2 * E]), pre[:, 2 * E:]], 1)
+        out.backward(dqkv)
+    got = ops.rope_bwd(dqkv.to(DEV, dtype).clone(), ang.cos().contiguous().to(DEV), ang.sin().contiguous().to(DEV),
+                       T, E, D, 0.125).float().cpu()
+    tol = dict(rtol=1e-2, atol=1e-2) if dtype == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got.numpy(), pre.grad.numpy(), **tol)

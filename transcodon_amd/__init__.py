@@ -10,5 +10,6 @@ from .model import ProteinBertModel  # noqa: F401
 from .modules import (ESM1bLayerNorm, RNA_2D_RobertaLMHead, RobertaLMHead,  # noqa: F401
                       TransformerLayer, gelu)
 from .multihead_attention import MultiheadAttention  # noqa: F401
-from .infer_utr import AA_tokenize, embed_sequence, optimize_codons, tokenize  # noqa: F401
+from .infer_utr import (AA_tokenize, embed_sequence, extract_embeddings, optimize_codons,  # noqa: F401
+                        tokenize)
 from .config import default_args, init_weights  # noqa: F401

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libtranscodon_hip.so")
 
 TC_F32, TC_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_QKV_ROPE = 0, 1, 2, 3
+EPI_PLAIN_F32, EPI_BIAS_GELU_SAVE, EPI_DGELU = 4, 5, 6
 PROF_GEMM, PROF_ATTN, PROF_LAYERNORM, PROF_EMBED, PROF_HEAD, PROF_DECODE = range(6)
 
 vp = C.c_void_p
@@ -53,6 +54,20 @@ _SIGNATURES = {
                                      C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "tc_codon_decode": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "tc_ce_loss_fwd_bwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp]),
+    "tc_mean_pool": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "tc_gemm_train": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.c_int, vp]),
+    "tc_transpose_cast": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp,
+                                    C.c_int, C.c_int, vp]),
+    "tc_reduce_slabs": (C.c_int, [vp, vp, C.c_int, C.c_long, C.c_int, vp]),
+    "tc_layernorm_bwd": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int,
+                                   C.c_float, vp]),
+    "tc_dgelu": (C.c_int, [C.c_int, vp, vp, vp, C.c_long, vp]),
+    "tc_head_logits_bwd": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
+                                     C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "tc_embed_bwd": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
+    "tc_rope_bwd": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                              C.c_float, vp]),
     "tc_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc), C.c_int, C.c_int]),
     "tc_encoder_forward": (C.c_int, [C.POINTER(EncoderDesc), vp, vp, C.c_int, C.c_int, vp, vp, vp,
                                      C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), vp, vp,

@@ -36,7 +36,11 @@ struct GemmParams {
     char *out;
     const float *rope_cos;
     const float *rope_sin;
+    const char *aux;       // TC_EPI_DGELU: pre-activation u, element type T, leading dimension ldo
+    char *out2;            // TC_EPI_BIAS_GELU_SAVE: pre-activation output, element type T
     long lda_bytes, ldw_bytes;
+    long slab_elems;       // split-K: f32 elements between the partial outputs of two splits
+    int splits;            // split-K factor of the small-tile kernel (1 = off)
     int ldo;
     int M, N, K;
     int tiles_m, tiles_n;
@@ -139,6 +143,33 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
     return r;
 }
 
+// d/dx gelu(x) = Phi(x) + x phi(x); Phi from the same erfc as gelu_fast (bf16 path) or exact erf.
+template <bool FAST>
+__device__ __forceinline__ float gelu_grad(float x) {
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    float cdf;
+    if constexpr (FAST) {
+        const float z = fabsf(x) * 0.70710678118654752440f;
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+        float poly = fmaf(t, 1.061405429f, -1.453152027f);
+        poly = fmaf(t, poly, 1.421413741f);
+        poly = fmaf(t, poly, -0.284496736f);
+        poly = fmaf(t, poly, 0.254829592f);
+        const float h = 0.5f * poly * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+        cdf = x < 0.f ? h : 1.0f - h;
+    } else {
+        cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    }
+    return fmaf(x, pdf, cdf);
+}
+template <typename T>
+__device__ __forceinline__ float load_elem(const char *base, long idx) {
+    if constexpr (sizeof(T) == 2)
+        return __builtin_bit_cast(float, (uint32_t)(*reinterpret_cast<const uint16_t *>(base + idx * 2)) << 16);
+    else
+        return *reinterpret_cast<const float *>(base + idx * 4);
+}
+
 // Epilogue arithmetic on 8 consecutive columns n..n+7 of row m; c = A.W^T (no bias yet).
 template <typename T, int EPI>
 __device__ __forceinline__ void epilogue8(const GemmParams &p, int m, int n, int section,
@@ -149,9 +180,16 @@ __device__ __forceinline__ void epilogue8(const GemmParams &p, int m, int n, int
     const long o = (long)m * p.ldo + n;
     if constexpr (EPI == TC_EPI_BIAS) {
         store8<T>(p.out, o, v);
-    } else if constexpr (EPI == TC_EPI_BIAS_GELU) {
+    } else if constexpr (EPI == TC_EPI_PLAIN_F32) {
+        store8<float>(p.out + (long)blockIdx.y * p.slab_elems * 4, o, v);
+    } else if constexpr (EPI == TC_EPI_BIAS_GELU || EPI == TC_EPI_BIAS_GELU_SAVE) {
+        if constexpr (EPI == TC_EPI_BIAS_GELU_SAVE) store8<T>(p.out2, o, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = sizeof(T) == 2 ? gelu_fast(v[j]) : tc_gelu(v[j]);
+        store8<T>(p.out, o, v);
+    } else if constexpr (EPI == TC_EPI_DGELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= gelu_grad<sizeof(T) == 2>(load_elem<T>(p.aux, o + j));
         store8<T>(p.out, o, v);
     } else if constexpr (EPI == TC_EPI_BIAS_RESIDUAL) {
         const f32x4 r0 = *reinterpret_cast<const f32x4 *>(p.residual + o);
@@ -181,6 +219,11 @@ __device__ __forceinline__ void epilogue8(const GemmParams &p, int m, int n, int
 }
 
 __device__ __forceinline__ void load_bias8(const float *bias, int n, float (&b)[8]) {
+    if (!bias) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = 0.f;
+        return;
+    }
     const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias + n);
     const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bias + n + 4);
 #pragma unroll
@@ -248,12 +291,15 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams p) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
-    for (int kt = 0; kt < p.nk; ++kt) {
+    // split-K: workgroup row blockIdx.y reduces k-tiles [k_begin, k_end) into its own f32 slab
+    const int k_begin = (int)((long)p.nk * blockIdx.y / p.splits);
+    const int k_end = (int)((long)p.nk * (blockIdx.y + 1) / p.splits);
+    if (k_begin < k_end) stage(0, k_begin);
+    for (int kt = k_begin; kt < k_end; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                         // tile kt landed; buffer (kt+1)&1 is free
-        if (kt + 1 < p.nk) stage((kt + 1) & 1, kt + 1);
-        const char *sbase = smem + (kt & 1) * STAGE_BYTES;
+        __syncthreads();                         // tile kt landed; the other buffer is free
+        if (kt + 1 < k_end) stage((kt - k_begin + 1) & 1, kt + 1);
+        const char *sbase = smem + ((kt - k_begin) & 1) * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             f32x4 a[4], b[4];
@@ -397,7 +443,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         {
             f32x4 bias[4];
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) bias[ni] = *reinterpret_cast<const f32x4 *>(p.bias + ncol0 + ni * 16);
+            for (int ni = 0; ni < 4; ++ni)
+                bias[ni] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + ncol0 + ni * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 if constexpr (kPreloadResidual) {
@@ -479,7 +526,42 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         // phase 2: all stores.
         prev_full = (tm * BM + BM) <= p.M;
         const int section = EPI == TC_EPI_QKV_ROPE ? (tn * BN) / p.E : 0;
-        if constexpr (EPI == TC_EPI_BIAS_GELU) {
+        if constexpr (EPI == TC_EPI_BIAS_GELU_SAVE) {
+            // pre-activation goes out first (kept for the backward pass), then GELU in place
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int m = mrow0 + mi * 16;
+                if (m < p.M) {
+                    const long orow = (long)m * p.ldo + ncol0;
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const f32x4 v = acc[ni][mi];
+                        u32x2 w;
+                        w[0] = tc_pack_bf16(v[0], v[1]);
+                        w[1] = tc_pack_bf16(v[2], v[3]);
+                        *reinterpret_cast<u32x2 *>(p.out2 + (orow + ni * 16) * 2) = w;
+                    }
+                }
+            }
+        }
+        if constexpr (EPI == TC_EPI_DGELU) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int m = mrow0 + mi * 16;
+                const char *up = p.aux + ((long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0) * 2;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const u32x2 w = *reinterpret_cast<const u32x2 *>(up + ni * 32);
+                    f32x4 v = acc[ni][mi];
+                    v[0] *= gelu_grad<true>(tc_bf16_lo(w[0]));
+                    v[1] *= gelu_grad<true>(tc_bf16_hi(w[0]));
+                    v[2] *= gelu_grad<true>(tc_bf16_lo(w[1]));
+                    v[3] *= gelu_grad<true>(tc_bf16_hi(w[1]));
+                    acc[ni][mi] = v;
+                }
+            }
+        }
+        if constexpr (EPI == TC_EPI_BIAS_GELU || EPI == TC_EPI_BIAS_GELU_SAVE) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -555,7 +637,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const f32x4 v = acc[ni][mi];
-                    if constexpr (EPI == TC_EPI_BIAS_RESIDUAL || sizeof(T) == 4) {
+                    if constexpr (EPI == TC_EPI_BIAS_RESIDUAL || EPI == TC_EPI_PLAIN_F32 || sizeof(T) == 4) {
                         *reinterpret_cast<f32x4 *>(p.out + (orow + ni * 16) * 4) = v;
                     } else {
                         u32x2 w;
@@ -636,7 +718,7 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
         }
         p.tiles_m = (p.M + k128::BM - 1) / k128::BM;
         p.tiles_n = p.N / k128::BN;
-        hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), k128::LDS_BYTES, stream, p);
+        hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(256), k128::LDS_BYTES, stream, p);
     }
     TC_CHECK_LAUNCH("tc_gemm");
     return TC_OK;
@@ -649,6 +731,9 @@ int dispatch(int epilogue, const GemmParams &p, bool big, hipStream_t stream) {
         case TC_EPI_BIAS_GELU: return launch<T, TC_EPI_BIAS_GELU>(p, big, stream);
         case TC_EPI_BIAS_RESIDUAL: return launch<T, TC_EPI_BIAS_RESIDUAL>(p, big, stream);
         case TC_EPI_QKV_ROPE: return launch<T, TC_EPI_QKV_ROPE>(p, big, stream);
+        case TC_EPI_PLAIN_F32: return launch<T, TC_EPI_PLAIN_F32>(p, big, stream);
+        case TC_EPI_BIAS_GELU_SAVE: return launch<T, TC_EPI_BIAS_GELU_SAVE>(p, big, stream);
+        case TC_EPI_DGELU: return launch<T, TC_EPI_DGELU>(p, big, stream);
     }
     tc_set_error("tc_gemm: unknown epilogue %d", epilogue);
     return TC_EINVAL;
@@ -660,14 +745,14 @@ int dispatch(int epilogue, const GemmParams &p, bool big, hipStream_t stream) {
 extern "C" void tc_debug_set_stamp_buffer(void *p) { g_stamps = static_cast<unsigned long long *>(p); }
 #endif
 
-extern "C" int tc_gemm(int dtype, int epilogue, const void *A, int lda, const void *W,
-                       const float *bias, const float *residual, void *out, int ldo, int M, int N,
-                       int K, float q_scale, const float *rope_cos, const float *rope_sin, int T,
-                       int head_dim, void *stream) {
+static int gemm_impl(int dtype, int epilogue, const void *A, int lda, const void *W, const float *bias,
+                     const float *residual, const void *aux, void *out, void *out2, int ldo, int M, int N,
+                     int K, int splits, float q_scale, const float *rope_cos, const float *rope_sin, int T,
+                     int head_dim, void *stream) {
     TC_REQUIRE(dtype == TC_BF16 || dtype == TC_F32, "tc_gemm: bad dtype %d", dtype);
     const int esz = dtype == TC_BF16 ? 2 : 4;
     const int kt = 128 / esz;
-    TC_REQUIRE(A && W && bias && out, "tc_gemm: null operand");
+    TC_REQUIRE(A && W && out, "tc_gemm: null operand");
     TC_REQUIRE(M > 0 && N > 0 && K > 0, "tc_gemm: empty problem M=%d N=%d K=%d", M, N, K);
     TC_REQUIRE(N % 128 == 0, "tc_gemm: N=%d must be a multiple of 128", N);
     TC_REQUIRE(K % kt == 0, "tc_gemm: K=%d must be a multiple of %d", K, kt);
@@ -675,12 +760,18 @@ extern "C" int tc_gemm(int dtype, int epilogue, const void *A, int lda, const vo
     TC_REQUIRE((lda * esz) % 16 == 0 && ldo % 8 == 0, "tc_gemm: leading dimensions must keep rows 16-byte aligned");
     TC_REQUIRE(tc_aligned16(A) && tc_aligned16(W) && tc_aligned16(out) && tc_aligned16(bias),
                "tc_gemm: operands must be 16-byte aligned");
+    TC_REQUIRE(bias || epilogue == TC_EPI_PLAIN_F32 || epilogue == TC_EPI_DGELU || epilogue == TC_EPI_BIAS_RESIDUAL,
+               "tc_gemm: this epilogue needs a bias vector");
+    TC_REQUIRE(splits >= 1 && splits <= 64, "tc_gemm: bad split count %d", splits);
+    TC_REQUIRE(splits == 1 || epilogue == TC_EPI_PLAIN_F32, "tc_gemm: split-K needs the plain f32 epilogue");
     GemmParams p{};
     p.A = static_cast<const char *>(A);
     p.W = static_cast<const char *>(W);
     p.bias = bias;
     p.residual = residual;
+    p.aux = static_cast<const char *>(aux);
     p.out = static_cast<char *>(out);
+    p.out2 = static_cast<char *>(out2);
     p.rope_cos = rope_cos;
     p.rope_sin = rope_sin;
     p.lda_bytes = (long)lda * esz;
@@ -690,9 +781,13 @@ extern "C" int tc_gemm(int dtype, int epilogue, const void *A, int lda, const vo
     p.nk = K / kt;
     p.T = T; p.head_dim = head_dim; p.E = N / 3;
     p.q_scale = q_scale;
+    p.splits = splits;
+    p.slab_elems = (long)M * ldo;
     if (epilogue == TC_EPI_BIAS_RESIDUAL) {
         TC_REQUIRE(residual && tc_aligned16(residual), "tc_gemm: residual epilogue needs an aligned residual");
     }
+    if (epilogue == TC_EPI_BIAS_GELU_SAVE) TC_REQUIRE(out2 && tc_aligned16(out2), "tc_gemm: GELU_SAVE needs out2");
+    if (epilogue == TC_EPI_DGELU) TC_REQUIRE(aux && tc_aligned16(aux), "tc_gemm: DGELU needs the pre-activation");
     if (epilogue == TC_EPI_QKV_ROPE) {
         TC_REQUIRE(N % 3 == 0 && (N / 3) % 128 == 0, "tc_gemm: qkv epilogue needs N = 3E with E %% 128 == 0");
         TC_REQUIRE(rope_cos && rope_sin && T > 0, "tc_gemm: qkv epilogue needs rope tables and T");
@@ -715,6 +810,7 @@ extern "C" int tc_gemm(int dtype, int epilogue, const void *A, int lda, const vo
                (long)M * lda * esz < (1L << 32) && (long)N * K * esz < (1L << 32);
     if (epilogue == TC_EPI_QKV_ROPE && (N / 3) % 256 != 0) big = false;
     if (dtype != TC_BF16) big = false;   // the f32 path is MFMA-rate bound (1/16 of bf16): small tile is enough
+    if (splits > 1) big = false;
     {
         static int force = -2;
         if (force == -2) { const char *e = getenv("TC_GEMM_TILE"); force = e ? atoi(e) : -1; }
@@ -723,4 +819,21 @@ extern "C" int tc_gemm(int dtype, int epilogue, const void *A, int lda, const vo
     hipStream_t s = static_cast<hipStream_t>(stream);
     TcProfScope prof(TC_PROF_GEMM, s, 2.0 * (double)M * (double)N * (double)K);
     return dtype == TC_BF16 ? dispatch<__bf16>(epilogue, p, big, s) : dispatch<float>(epilogue, p, big, s);
+}
+
+extern "C" int tc_gemm(int dtype, int epilogue, const void *A, int lda, const void *W, const float *bias,
+                       const float *residual, void *out, int ldo, int M, int N, int K, float q_scale,
+                       const float *rope_cos, const float *rope_sin, int T, int head_dim, void *stream) {
+    TC_REQUIRE(epilogue >= TC_EPI_BIAS && epilogue <= TC_EPI_QKV_ROPE, "tc_gemm: unknown epilogue %d", epilogue);
+    return gemm_impl(dtype, epilogue, A, lda, W, bias, residual, nullptr, out, nullptr, ldo, M, N, K, 1, q_scale,
+                     rope_cos, rope_sin, T, head_dim, stream);
+}
+
+extern "C" int tc_gemm_train(int dtype, int epilogue, const void *A, int lda, const void *W, const float *bias,
+                             const void *aux, void *out, void *out2, int ldo, int M, int N, int K, int splits,
+                             void *stream) {
+    TC_REQUIRE(epilogue == TC_EPI_PLAIN_F32 || epilogue == TC_EPI_BIAS_GELU_SAVE || epilogue == TC_EPI_DGELU,
+               "tc_gemm_train: unknown epilogue %d", epilogue);
+    return gemm_impl(dtype, epilogue, A, lda, W, bias, nullptr, aux, out, out2, ldo, M, N, K, splits, 0.f, nullptr,
+                     nullptr, 0, 0, stream);
 }

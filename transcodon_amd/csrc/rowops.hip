@@ -299,7 +299,40 @@ __global__ __launch_bounds__(256) void ce_kernel(const float *__restrict__ logit
     }
 }
 
+// ---- masked mean pooling -------------------------------------------------------------------
+// grid (ceil(E/256), B): 64 row-lanes x 4 columns per thread... one thread per column, rows looped
+__global__ __launch_bounds__(256) void mean_pool_kernel(const float *__restrict__ rep,
+                                                        const int32_t *__restrict__ start,
+                                                        const int32_t *__restrict__ len,
+                                                        float *__restrict__ pooled, int T, int E) {
+    const int b = blockIdx.y;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= E) return;
+    int s0 = start[b], n = len[b];
+    s0 = s0 < 0 ? 0 : s0;
+    if (s0 + n > T) n = T - s0;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float *base = rep + ((long)b * T + s0) * E + col;
+    int t = 0;
+    for (; t + 4 <= n; t += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += base[(long)(t + j) * E];
+    }
+    for (; t < n; ++t) acc[0] += base[(long)t * E];
+    pooled[(long)b * E + col] = n > 0 ? ((acc[0] + acc[1]) + (acc[2] + acc[3])) / (float)n : 0.f;
+}
+
 }  // namespace
+
+extern "C" int tc_mean_pool(const float *rep, const int32_t *start, const int32_t *len, float *pooled,
+                            int B, int T, int E, void *stream) {
+    TC_REQUIRE(rep && start && len && pooled, "tc_mean_pool: null operand");
+    TC_REQUIRE(B > 0 && T > 0 && E > 0 && B <= 65535, "tc_mean_pool: bad shape B=%d T=%d E=%d", B, T, E);
+    hipLaunchKernelGGL(mean_pool_kernel, dim3((E + 255) / 256, B), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), rep, start, len, pooled, T, E);
+    TC_CHECK_LAUNCH("tc_mean_pool");
+    return TC_OK;
+}
 
 extern "C" int tc_embed_fwd(const int32_t *tokens, const int32_t *species, const float *tok_table,
                             const float *species_table, float *x, uint8_t *pad_flags,

@@ -1,0 +1,456 @@
+// Backward-pass row kernels of the training step: transposes for the weight-gradient GEMMs,
+// split-K slab reduction, LayerNorm / GELU / thin-head / embedding / rotary backward.
+// All of them are HBM-bound; column reductions (bias, LayerNorm affine, thin-head weight
+// gradients) are accumulated per wave in registers, combined per workgroup through LDS and
+// added to the f32 gradient buffers with one atomic per column and workgroup.
+#include "common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<uint16_t>(uint16_t v) {
+    return __builtin_bit_cast(float, (uint32_t)v << 16);
+}
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ uint16_t from_f32<uint16_t>(float v) {
+    return __builtin_bit_cast(uint16_t, (__bf16)v);
+}
+
+// ---- transpose + cast (+ column sums) ------------------------------------------------------
+// in [M,N] (ld_in) -> out_t [N, ldt] with out_t[n][m] = in[m][n]; columns m in [M, ldt) are
+// written as zeros so the token dimension can serve as a padded GEMM reduction dimension.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose_kernel(const TI *__restrict__ in, long ld_in,
+                                                        TO *__restrict__ out_t, long ldt,
+                                                        TO *__restrict__ out_rm, long ld_rm,
+                                                        float *__restrict__ colsum, int M, int N) {
+    __shared__ float tile[64][65];
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
+    float csum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = ty * 16 + i;
+        const int m = m0 + r, n = n0 + tx;
+        float v = 0.f;
+        if (m < M && n < N) {
+            v = to_f32<TI>(in[(long)m * ld_in + n]);
+            if (out_rm) out_rm[(long)m * ld_rm + n] = from_f32<TO>(v);
+        }
+        tile[r][tx] = v;
+        csum += v;
+    }
+    if (colsum) {
+        __shared__ float part[4][64];
+        part[ty][tx] = csum;
+        __syncthreads();
+        if (ty == 0 && n0 + tx < N)
+            atomicAdd(colsum + n0 + tx, (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]));
+    } else {
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = ty * 16 + i;                // column of the input tile = row of the output
+        const int n = n0 + c, m = m0 + tx;
+        if (n < N && m < ldt) out_t[(long)n * ldt + m] = from_f32<TO>(tile[tx][c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs,
+                                                           float *__restrict__ out, int S, long n,
+                                                           int accumulate) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 acc = accumulate ? *reinterpret_cast<const f32x4 *>(out + i) : f32x4{0, 0, 0, 0};
+    for (int s = 0; s < S; ++s) acc += *reinterpret_cast<const f32x4 *>(slabs + (long)s * n + i);
+    *reinterpret_cast<f32x4 *>(out + i) = acc;
+}
+
+// ---- LayerNorm backward ----------------------------------------------------------------------
+template <typename TX, int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX *__restrict__ x, long ldx,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ dy,
+                                                            float *__restrict__ dx, int accumulate,
+                                                            float *__restrict__ dgamma,
+                                                            float *__restrict__ dbeta, int M, int E,
+                                                            float eps) {
+    __shared__ float red[2][NCH * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2 * NCH * 256; i += 256) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+    f32x4 g_[NCH], dg[NCH], db[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        g_[c] = col < E ? *reinterpret_cast<const f32x4 *>(gamma + col) : f32x4{0, 0, 0, 0};
+        dg[c] = f32x4{0, 0, 0, 0};
+        db[c] = f32x4{0, 0, 0, 0};
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        f32x4 xv[NCH], dyv[NCH];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < E) {
+                const TX *px = x + (long)row * ldx + col;
+                xv[c] = f32x4{to_f32<TX>(px[0]), to_f32<TX>(px[1]), to_f32<TX>(px[2]), to_f32<TX>(px[3])};
+                dyv[c] = *reinterpret_cast<const f32x4 *>(dy + (long)row * E + col);
+            } else {
+                xv[c] = f32x4{0, 0, 0, 0};
+                dyv[c] = f32x4{0, 0, 0, 0};
+            }
+            s += (xv[c][0] + xv[c][1]) + (xv[c][2] + xv[c][3]);
+        }
+        const float mean = tc_wave_sum(s) / (float)E;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < E) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = xv[c][j] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        const float rstd = rsqrtf(tc_wave_sum(q) / (float)E + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < E) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (xv[c][j] - mean) * rstd;
+                    const float gy = dyv[c][j] * g_[c][j];
+                    xv[c][j] = xh;
+                    dg[c][j] += dyv[c][j] * xh;
+                    db[c][j] += dyv[c][j];
+                    dyv[c][j] = gy;
+                    s1 += gy;
+                    s2 += gy * xh;
+                }
+            }
+        }
+        const float m1 = tc_wave_sum(s1) / (float)E, m2 = tc_wave_sum(s2) / (float)E;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < E) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rstd * (dyv[c][j] - m1 - xv[c][j] * m2);
+                float *po = dx + (long)row * E + col;
+                if (accumulate) o += *reinterpret_cast<const f32x4 *>(po);
+                *reinterpret_cast<f32x4 *>(po) = o;
+            }
+        }
+    }
+    // workgroup reduction of the affine gradients, then one atomic per column
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(&red[0][c * 256 + lane * 4 + j], dg[c][j]);
+            atomicAdd(&red[1][c * 256 + lane * 4 + j], db[c][j]);
+        }
+    (void)wave;
+    __syncthreads();
+    for (int col = threadIdx.x; col < E; col += 256) {
+        atomicAdd(dgamma + col, red[0][col]);
+        atomicAdd(dbeta + col, red[1][col]);
+    }
+}
+
+// ---- GELU backward (elementwise) ---------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dgelu_kernel(const float *__restrict__ dy, const T *__restrict__ u,
+                                                    T *__restrict__ out, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x = to_f32<T>(u[i + j]);
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        out[i + j] = from_f32<T>(g[j] * fmaf(x, pdf, cdf));
+    }
+}
+
+// ---- thin head backward ------------------------------------------------------------------------
+// logits = LN(g) W^T + b with W [V,E]:  d_ln = dlogits W,  dW += dlogits^T LN(g),  db += colsum.
+template <typename T, int NCH, int V>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T *__restrict__ g, int ldg, int col0,
+                                                       const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta,
+                                                       const float *__restrict__ W,
+                                                       const float *__restrict__ dlogits,
+                                                       float *__restrict__ d_ln, float *__restrict__ dW,
+                                                       float *__restrict__ dbias, int M, int E, float eps) {
+    __shared__ float red[V][NCH * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < V * NCH * 256; i += 256) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+    f32x4 gm[NCH], bt[NCH], acc[V][NCH];
+    float accb = 0.f;                                  // lane v < V keeps dbias[v]
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        gm[c] = col < E ? *reinterpret_cast<const f32x4 *>(gamma + col) : f32x4{0, 0, 0, 0};
+        bt[c] = col < E ? *reinterpret_cast<const f32x4 *>(beta + col) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v][c] = f32x4{0, 0, 0, 0};
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const T *src = g + (long)row * ldg + col0;
+        f32x4 xv[NCH];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 256 + lane * 4;
+            xv[c] = col < E ? f32x4{to_f32<T>(src[col]), to_f32<T>(src[col + 1]), to_f32<T>(src[col + 2]),
+                                    to_f32<T>(src[col + 3])}
+                            : f32x4{0, 0, 0, 0};
+            s += (xv[c][0] + xv[c][1]) + (xv[c][2] + xv[c][3]);
+        }
+        const float mean = tc_wave_sum(s) / (float)E;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < E) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = xv[c][j] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        const float rstd = rsqrtf(tc_wave_sum(q) / (float)E + eps);
+        float dl[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) dl[v] = dlogits[(long)row * V + v];
+        if (lane < V) accb += dlogits[(long)row * V + lane];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < E) {
+                f32x4 ln, o = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ln[j] = (xv[c][j] - mean) * rstd * gm[c][j] + bt[c][j];
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(W + (long)v * E + col);
+                    o += wv * dl[v];
+                    acc[v][c] += ln * dl[v];
+                }
+                *reinterpret_cast<f32x4 *>(d_ln + (long)row * E + col) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(&red[v][c * 256 + lane * 4 + j], acc[v][c][j]);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < V * E; idx += 256) {
+        const int v = idx / E, col = idx - v * E;
+        atomicAdd(dW + idx, red[v][col]);
+    }
+    if (lane < V) atomicAdd(dbias + lane, accb);
+}
+
+// ---- embedding backward -------------------------------------------------------------------------
+// One workgroup per sequence: sums dx over the sequence's non-pad rows per token id (in LDS, each
+// thread owns its columns) and over all non-pad rows for the species row.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t *__restrict__ tokens,
+                                                        const int32_t *__restrict__ species,
+                                                        const float *__restrict__ dx,
+                                                        float *__restrict__ d_tok,
+                                                        float *__restrict__ d_sp, int T, int E, int vocab,
+                                                        int n_species, int pad_idx) {
+    extern __shared__ float s_tok[];                 // [vocab][E]
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < vocab * E; i += 256) s_tok[i] = 0.f;
+    __syncthreads();
+    const int sp = species[b];
+    for (int col = threadIdx.x; col < E; col += 256) {
+        float ssum = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const int tok = tokens[(long)b * T + t];
+            if (tok == pad_idx || tok < 0 || tok >= vocab) continue;
+            const float v = dx[((long)b * T + t) * E + col];
+            s_tok[tok * E + col] += v;
+            ssum += v;
+        }
+        if (sp >= 0 && sp < n_species) atomicAdd(d_sp + (long)sp * E + col, ssum);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < vocab * E; i += 256) {
+        const float v = s_tok[i];
+        if (v != 0.f) atomicAdd(d_tok + i, v);
+    }
+}
+
+// ---- rotary backward (in place on the q and k sections of d_qkv) -----------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rope_bwd_kernel(T *__restrict__ dqkv, long ld,
+                                                       const float *__restrict__ cs,
+                                                       const float *__restrict__ sn, int M, int Tn, int E,
+                                                       int head_dim, float q_scale) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;     // pair index over [M, E] (q and k sections)
+    const long pairs_per_row = E;                               // 2E columns / 2
+    if (idx >= (long)M * pairs_per_row) return;
+    const int m = (int)(idx / pairs_per_row);
+    const int pc = (int)(idx - (long)m * pairs_per_row);        // pair column in [0, E)
+    const int col = pc * 2;                                     // column in [0, 2E)
+    const int pi = (col % head_dim) >> 1;
+    const long t = (long)(m % Tn) * (head_dim >> 1) + pi;
+    const float c = cs[t], s = sn[t];
+    T *p = dqkv + (long)m * ld + col;
+    const float d0 = to_f32<T>(p[0]), d1 = to_f32<T>(p[1]);
+    const float sc = col < E ? q_scale : 1.0f;
+    p[0] = from_f32<T>((d0 * c + d1 * s) * sc);
+    p[1] = from_f32<T>((d1 * c - d0 * s) * sc);
+}
+
+}  // namespace
+
+extern "C" int tc_transpose_cast(int in_dtype, int out_dtype, const void *in, int ld_in, void *out_t, int ldt,
+                                 void *out_rowmajor, int ld_rm, float *colsum, int M, int N, void *stream) {
+    TC_REQUIRE(in && out_t && M > 0 && N > 0 && ld_in >= N && ldt >= M, "tc_transpose_cast: bad arguments");
+    TC_REQUIRE((in_dtype == TC_F32 || in_dtype == TC_BF16) && (out_dtype == TC_F32 || out_dtype == TC_BF16),
+               "tc_transpose_cast: bad dtype");
+    TC_REQUIRE(!(in_dtype == TC_BF16 && out_dtype == TC_F32), "tc_transpose_cast: bf16 -> f32 is not built");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((ldt + 63) / 64, (N + 63) / 64), block(256);
+    if (in_dtype == TC_F32 && out_dtype == TC_F32)
+        hipLaunchKernelGGL((transpose_kernel<float, float>), grid, block, 0, s, static_cast<const float *>(in),
+                           (long)ld_in, static_cast<float *>(out_t), (long)ldt, static_cast<float *>(out_rowmajor),
+                           (long)ld_rm, colsum, M, N);
+    else if (in_dtype == TC_F32)
+        hipLaunchKernelGGL((transpose_kernel<float, uint16_t>), grid, block, 0, s, static_cast<const float *>(in),
+                           (long)ld_in, static_cast<uint16_t *>(out_t), (long)ldt,
+                           static_cast<uint16_t *>(out_rowmajor), (long)ld_rm, colsum, M, N);
+    else
+        hipLaunchKernelGGL((transpose_kernel<uint16_t, uint16_t>), grid, block, 0, s,
+                           static_cast<const uint16_t *>(in), (long)ld_in, static_cast<uint16_t *>(out_t), (long)ldt,
+                           static_cast<uint16_t *>(out_rowmajor), (long)ld_rm, colsum, M, N);
+    TC_CHECK_LAUNCH("tc_transpose_cast");
+    return TC_OK;
+}
+
+extern "C" int tc_reduce_slabs(const float *slabs, float *out, int S, long n, int accumulate, void *stream) {
+    TC_REQUIRE(slabs && out && S >= 1 && n > 0 && n % 4 == 0, "tc_reduce_slabs: bad arguments");
+    TC_REQUIRE(tc_aligned16(slabs) && tc_aligned16(out), "tc_reduce_slabs: misaligned operand");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), slabs, out, S, n, accumulate);
+    TC_CHECK_LAUNCH("tc_reduce_slabs");
+    return TC_OK;
+}
+
+extern "C" int tc_layernorm_bwd(int x_dtype, const void *x, int ldx, const float *gamma, const float *dy,
+                                float *dx, int accumulate, float *dgamma, float *dbeta, int M, int E, float eps,
+                                void *stream) {
+    TC_REQUIRE(x && gamma && dy && dx && dgamma && dbeta, "tc_layernorm_bwd: null operand");
+    TC_REQUIRE(M > 0 && E > 0 && E % 4 == 0 && E <= 1024 && ldx >= E, "tc_layernorm_bwd: bad shape M=%d E=%d", M, E);
+    TC_REQUIRE(x_dtype == TC_F32 || x_dtype == TC_BF16, "tc_layernorm_bwd: bad dtype");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int blocks = (M + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    const int nch = (E + 255) / 256;
+#define TC_LNB(TX, N)                                                                                     \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TX, N>), dim3(blocks), dim3(256), 0, s, static_cast<const TX *>(x), \
+                       (long)ldx, gamma, dy, dx, accumulate, dgamma, dbeta, M, E, eps)
+    if (x_dtype == TC_F32) {
+        switch (nch) { case 1: TC_LNB(float, 1); break; case 2: TC_LNB(float, 2); break;
+                       case 3: TC_LNB(float, 3); break; default: TC_LNB(float, 4); break; }
+    } else {
+        switch (nch) { case 1: TC_LNB(uint16_t, 1); break; case 2: TC_LNB(uint16_t, 2); break;
+                       case 3: TC_LNB(uint16_t, 3); break; default: TC_LNB(uint16_t, 4); break; }
+    }
+#undef TC_LNB
+    TC_CHECK_LAUNCH("tc_layernorm_bwd");
+    return TC_OK;
+}
+
+extern "C" int tc_dgelu(int dtype, const float *dy, const void *u, void *out, long n, void *stream) {
+    TC_REQUIRE(dy && u && out && n > 0 && n % 4 == 0, "tc_dgelu: bad arguments");
+    TC_REQUIRE(dtype == TC_F32 || dtype == TC_BF16, "tc_dgelu: bad dtype");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((n / 4 + 255) / 256)), block(256);
+    if (dtype == TC_F32)
+        hipLaunchKernelGGL(dgelu_kernel<float>, grid, block, 0, s, dy, static_cast<const float *>(u),
+                           static_cast<float *>(out), n);
+    else
+        hipLaunchKernelGGL(dgelu_kernel<uint16_t>, grid, block, 0, s, dy, static_cast<const uint16_t *>(u),
+                           static_cast<uint16_t *>(out), n);
+    TC_CHECK_LAUNCH("tc_dgelu");
+    return TC_OK;
+}
+
+extern "C" int tc_head_logits_bwd(int dtype, const void *g, int ldg, int col0, const float *gamma,
+                                  const float *beta, const float *W, const float *dlogits, float *d_ln,
+                                  float *dW, float *dbias, int M, int E, int V, float eps, void *stream) {
+    TC_REQUIRE(g && gamma && beta && W && dlogits && d_ln && dW && dbias, "tc_head_logits_bwd: null operand");
+    TC_REQUIRE(M > 0 && E > 0 && E % 4 == 0 && E <= 768 && (V == 3 || V == 10),
+               "tc_head_logits_bwd: unsupported shape E=%d V=%d (E <= 768, V in {3,10})", E, V);
+    TC_REQUIRE(dtype == TC_F32 || dtype == TC_BF16, "tc_head_logits_bwd: bad dtype");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int blocks = (M + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    const int nch = (E + 255) / 256;
+#define TC_HB(TY, N, VV)                                                                                   \
+    hipLaunchKernelGGL((head_bwd_kernel<TY, N, VV>), dim3(blocks), dim3(256), 0, s, static_cast<const TY *>(g), \
+                       ldg, col0, gamma, beta, W, dlogits, d_ln, dW, dbias, M, E, eps)
+#define TC_HB_V(TY, N) do { if (V == 3) TC_HB(TY, N, 3); else TC_HB(TY, N, 10); } while (0)
+    if (dtype == TC_F32) {
+        switch (nch) { case 1: TC_HB_V(float, 1); break; case 2: TC_HB_V(float, 2); break; default: TC_HB_V(float, 3); break; }
+    } else {
+        switch (nch) { case 1: TC_HB_V(uint16_t, 1); break; case 2: TC_HB_V(uint16_t, 2); break; default: TC_HB_V(uint16_t, 3); break; }
+    }
+#undef TC_HB_V
+#undef TC_HB
+    TC_CHECK_LAUNCH("tc_head_logits_bwd");
+    return TC_OK;
+}
+
+extern "C" int tc_embed_bwd(const int32_t *tokens, const int32_t *species, const float *dx, float *d_tok_table,
+                            float *d_species_table, int B, int T, int E, int vocab, int n_species, int pad_idx,
+                            void *stream) {
+    TC_REQUIRE(tokens && species && dx && d_tok_table && d_species_table, "tc_embed_bwd: null operand");
+    TC_REQUIRE(B > 0 && T > 0 && E > 0 && vocab > 0 && (size_t)vocab * E * 4 <= 64 * 1024,
+               "tc_embed_bwd: bad shape (vocab*E*4 must fit 64 KiB of LDS)");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B), dim3(256), (size_t)vocab * E * 4, static_cast<hipStream_t>(stream),
+                       tokens, species, dx, d_tok_table, d_species_table, T, E, vocab, n_species, pad_idx);
+    TC_CHECK_LAUNCH("tc_embed_bwd");
+    return TC_OK;
+}
+
+extern "C" int tc_rope_bwd(int dtype, void *dqkv, int ld, const float *rope_cos, const float *rope_sin, int M,
+                           int T, int E, int head_dim, float q_scale, void *stream) {
+    TC_REQUIRE(dqkv && rope_cos && rope_sin && M > 0 && T > 0 && E > 0 && head_dim > 0 && head_dim % 2 == 0 &&
+                   E % head_dim == 0 && ld >= 2 * E,
+               "tc_rope_bwd: bad arguments");
+    TC_REQUIRE(dtype == TC_F32 || dtype == TC_BF16, "tc_rope_bwd: bad dtype");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long n = (long)M * E;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (dtype == TC_F32)
+        hipLaunchKernelGGL(rope_bwd_kernel<float>, grid, block, 0, s, static_cast<float *>(dqkv), (long)ld, rope_cos,
+                           rope_sin, M, T, E, head_dim, q_scale);
+    else
+        hipLaunchKernelGGL(rope_bwd_kernel<uint16_t>, grid, block, 0, s, static_cast<uint16_t *>(dqkv), (long)ld,
+                           rope_cos, rope_sin, M, T, E, head_dim, q_scale);
+    TC_CHECK_LAUNCH("tc_rope_bwd");
+    return TC_OK;
+}

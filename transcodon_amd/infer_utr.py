@@ -94,6 +94,52 @@ def embed_sequence(model, utr_seq, sequence: Union[str, WithUtr_CodonSequence_in
     return output["representations"], cds_logits, rna
 
 
+def extract_embeddings(model, cds_seqs: Sequence[str], organisms: Sequence[Union[int, str]],
+                       max_batch_tokens: int = 1 << 17, max_positions: int = 6146,
+                       pooled: bool = True):
+    """Embedding extraction (reference transcodon/infer_embedding.py: representations[12] of
+    `<cls> cds <eos>`, one sequence per call) for many coding sequences at once.
+
+    Sequences (DNA or RNA letters, T is read as U) are sorted by length, packed into padded
+    batches of at most ``max_batch_tokens`` tokens and run with key-padding-aware attention.
+    Returns a [N, E] float tensor on the CPU with the mean of the final-layer states over the
+    CDS positions (the pooling hinted at in infer_embedding.py:145), or, with pooled=False, a
+    list of [len_i, E] tensors of the CDS positions."""
+    from .sequence import CodonSequence
+    dev = _model_device(model)
+    L = model.num_layers
+    enc = [_ALPHABET.encode(CodonSequence("", s).seq)[:max_positions] for s in cds_seqs]
+    species = [_species_id(o) for o in organisms]
+    order = sorted(range(len(enc)), key=lambda k: len(enc[k]))
+    out = [None] * len(enc)
+    pos = 0
+    while pos < len(order):
+        width, chunk = 0, []
+        while pos < len(order):
+            w = max(width, len(enc[order[pos]]))
+            if chunk and w * (len(chunk) + 1) > max_batch_tokens:
+                break
+            chunk.append(order[pos])
+            width = w
+            pos += 1
+        tok = torch.full((len(chunk), width), _ALPHABET.padding_idx, dtype=torch.int32)
+        for r, k in enumerate(chunk):
+            tok[r, :len(enc[k])] = torch.tensor(enc[k], dtype=torch.int32)
+        with torch.no_grad():
+            rep = model(tok.to(dev), torch.tensor([species[k] for k in chunk], dtype=torch.int32, device=dev),
+                        repr_layers=[L])["representations"][L]
+        lens = torch.tensor([max(len(enc[k]) - 2, 0) for k in chunk], dtype=torch.int32, device=dev)
+        if pooled:
+            p = ops.mean_pool(rep, torch.ones_like(lens), lens).cpu()
+            for r, k in enumerate(chunk):
+                out[k] = p[r]
+        else:
+            rep = rep.cpu()
+            for r, k in enumerate(chunk):
+                out[k] = rep[r, 1:1 + int(lens[r])].clone()
+    return torch.stack(out) if pooled else out
+
+
 def optimize_codons(model, proteins: Sequence[str], organisms: Sequence[Union[int, str]],
                     utrs: Optional[Sequence[str]] = None, max_batch_tokens: int = 1 << 17,
                     max_aa: int = 2048) -> List[str]:

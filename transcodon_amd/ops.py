@@ -116,6 +116,17 @@ def head_logits(g, col0, E, gamma, beta, W, bias, eps=1e-5):
     return out
 
 
+def mean_pool(rep, start, length):
+    """rep f32 [B,T,E]; start,length int32 [B] -> pooled f32 [B,E] (tc_mean_pool)."""
+    start = start.to(torch.int32).contiguous()
+    length = length.to(torch.int32).contiguous()
+    _dev(rep, start, length)
+    B, T, E = rep.shape
+    out = torch.empty(B, E, dtype=torch.float32, device=rep.device)
+    check(_lib.load().tc_mean_pool(_p(rep), _p(start), _p(length), _p(out), B, T, E, _stream()), "tc_mean_pool")
+    return out
+
+
 def encode_amino_acids(aa_seq: str) -> bytes:
     """Protein letters -> tc_codon_decode codes; unknown letters raise KeyError like
     the reference's dict lookup (infer_utr.py:108)."""
@@ -146,3 +157,98 @@ def ce_loss(logits2d, labels, want_grad=False, grad_scale=1.0):
     check(_lib.load().tc_ce_loss_fwd_bwd(_p(logits2d), _p(labels), _p(loss), _p(cnt), _p(dl),
                                          grad_scale, M, V, _stream()), "tc_ce_loss_fwd_bwd")
     return loss, cnt, dl
+
+
+# ---- training-step kernels -----------------------------------------------------------------
+def gemm_train(a, w, epilogue, bias=None, aux=None, out=None, out2=None, splits=1):
+    """tc_gemm_train: EPI_PLAIN_F32 (f32 out, optional split-K slabs [splits, M, N]),
+    EPI_BIAS_GELU_SAVE (returns (gelu, pre)), EPI_DGELU (aux = pre-activation)."""
+    _dev(a, w, bias, aux, out, out2)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.dtype == w.dtype
+    if out is None:
+        if epilogue == _lib.EPI_PLAIN_F32:
+            out = torch.empty((splits, M, N) if splits > 1 else (M, N), dtype=torch.float32, device=a.device)
+        else:
+            out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    if epilogue == _lib.EPI_BIAS_GELU_SAVE and out2 is None:
+        out2 = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    check(_lib.load().tc_gemm_train(_dt(a), epilogue, _p(a), a.stride(0), _p(w), _p(bias), _p(aux), _p(out),
+                                    _p(out2), N, M, N, K, splits, _stream()), "tc_gemm_train")
+    return (out, out2) if epilogue == _lib.EPI_BIAS_GELU_SAVE else out
+
+
+def transpose_cast(x, out_dtype, want_rowmajor=False, want_colsum=False, colsum=None, pad_to=64):
+    """x [M,N] -> (x^T [N, ldt] zero-padded to a multiple of pad_to columns, row-major copy or
+    None, column sums f32 [N] or None)."""
+    _dev(x, colsum)
+    M, N = x.shape
+    ldt = (M + pad_to - 1) // pad_to * pad_to
+    out_t = torch.empty(N, ldt, dtype=out_dtype, device=x.device)
+    rm = torch.empty(M, N, dtype=out_dtype, device=x.device) if want_rowmajor else None
+    if want_colsum and colsum is None:
+        colsum = torch.zeros(N, dtype=torch.float32, device=x.device)
+    check(_lib.load().tc_transpose_cast(_dt(x), TC_BF16 if out_dtype == torch.bfloat16 else TC_F32, _p(x),
+                                        x.stride(0), _p(out_t), ldt, _p(rm), N, _p(colsum), M, N, _stream()),
+          "tc_transpose_cast")
+    return out_t, rm, colsum
+
+
+def reduce_slabs(slabs, out=None, accumulate=False):
+    _dev(slabs, out)
+    S = slabs.shape[0]
+    n = slabs[0].numel()
+    if out is None:
+        out = torch.empty_like(slabs[0])
+        accumulate = False
+    check(_lib.load().tc_reduce_slabs(_p(slabs), _p(out), S, n, int(accumulate), _stream()), "tc_reduce_slabs")
+    return out
+
+
+def layernorm_bwd(x, gamma, dy, dgamma, dbeta, dx=None, accumulate=False, eps=1e-5):
+    """x may be a column slice of a wider buffer (row stride = its leading dimension)."""
+    _dev(gamma, dy, dgamma, dbeta, dx)
+    if not x.is_cuda or x.stride(1) != 1:
+        raise ValueError("x must be a GPU tensor with unit column stride")
+    M, E = dy.shape
+    if dx is None:
+        dx = torch.empty(M, E, dtype=torch.float32, device=dy.device)
+        accumulate = False
+    check(_lib.load().tc_layernorm_bwd(_dt(x), _p(x), x.stride(0), _p(gamma), _p(dy), _p(dx), int(accumulate),
+                                       _p(dgamma), _p(dbeta), M, E, eps, _stream()), "tc_layernorm_bwd")
+    return dx
+
+
+def dgelu(dy, u):
+    _dev(dy, u)
+    out = torch.empty_like(u)
+    check(_lib.load().tc_dgelu(_dt(u), _p(dy), _p(u), _p(out), u.numel(), _stream()), "tc_dgelu")
+    return out
+
+
+def head_logits_bwd(g, col0, E, gamma, beta, W, dlogits, dW, dbias, eps=1e-5):
+    _dev(g, gamma, beta, W, dlogits, dW, dbias)
+    M, V = dlogits.shape
+    d_ln = torch.empty(M, E, dtype=torch.float32, device=g.device)
+    check(_lib.load().tc_head_logits_bwd(_dt(g), _p(g), g.stride(0), col0, _p(gamma), _p(beta), _p(W), _p(dlogits),
+                                         _p(d_ln), _p(dW), _p(dbias), M, E, V, eps, _stream()),
+          "tc_head_logits_bwd")
+    return d_ln
+
+
+def embed_bwd(tokens, species, dx, d_tok, d_sp, pad_idx=1):
+    tokens = tokens.to(torch.int32).contiguous()
+    species = species.to(torch.int32).contiguous()
+    _dev(tokens, species, dx, d_tok, d_sp)
+    B, T = tokens.shape
+    E = dx.shape[-1]
+    check(_lib.load().tc_embed_bwd(_p(tokens), _p(species), _p(dx), _p(d_tok), _p(d_sp), B, T, E, d_tok.shape[0],
+                                   d_sp.shape[0], pad_idx, _stream()), "tc_embed_bwd")
+
+
+def rope_bwd(dqkv, cos, sin, T, E, head_dim, q_scale):
+    _dev(dqkv, cos, sin)
+    check(_lib.load().tc_rope_bwd(_dt(dqkv), _p(dqkv), dqkv.stride(0), _p(cos), _p(sin), dqkv.shape[0], T, E,
+                                  head_dim, q_scale, _stream()), "tc_rope_bwd")
+    return dqkv
