@@ -241,6 +241,26 @@ int tc_embed_bwd(const int32_t *tokens, const int32_t *species, const float *dx,
 int tc_rope_bwd(int dtype, void *dqkv, int ld, const float *rope_cos, const float *rope_sin, int M, int T,
                 int E, int head_dim, float q_scale, void *stream);
 
+/*
+ * tc_attn_fwd that also returns lse[b,h,t] = log sum_k exp(score[t,k]) (natural log, f32 [B,H,T];
+ * +inf for a query without any valid key), the only softmax state the backward needs.
+ */
+int tc_attn_fwd_train(int dtype, const void *qkv, int ldq, const uint64_t *key_words, void *out, float *lse,
+                      int B, int T, int H, int D, void *stream);
+
+/*
+ * Backward of tc_attn_fwd, i.e. of transcodon/multihead_attention.py:362-398 as autograd would
+ * differentiate it: given qkv (as passed to the forward), out, lse and d_out [B*T, E],
+ *   d_qkv[:, 0:E] = dS K,  d_qkv[:, E:2E] = dS^T Q,  d_qkv[:, 2E:3E] = P^T d_out
+ * with P = exp(S - lse) (0 at padded keys) and dS = P o (d_out V^T - delta),
+ * delta[b,h,t] = sum_d d_out o out (f32 [B,H,T] scratch supplied by the caller, overwritten).
+ * The gradients are with respect to the scaled, rotated q and rotated k: follow with
+ * tc_rope_bwd.  d_qkv [B*T, ldg] has the element type `dtype`.  D must be 64.
+ */
+int tc_attn_bwd(int dtype, const void *qkv, int ldq, const uint64_t *key_words, const void *out,
+                const void *d_out, const float *lse, float *delta, void *d_qkv, int ldg, int B, int T, int H,
+                int D, void *stream);
+
 /* ---- whole-encoder convenience (one call per forward) ---------------------------- */
 
 typedef struct tc_layer_weights {

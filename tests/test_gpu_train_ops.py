@@ -168,3 +168,55 @@ def test_rope_backward(dtype):
                        T, E, D, 0.125).float().cpu()
     tol = dict(rtol=1e-2, atol=1e-2) if dtype == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(got.numpy(), pre.grad.numpy(), **tol)
+
+
+def _ref_attention(qkv, B, T, H, pad):
+    """Plain attention on [B*T, 3E] (q already scaled/rotated), the maths of
+    transcodon/multihead_attention.py:362-398."""
+    E = H * 64
+    q, k, v = (qkv[:, i * E:(i + 1) * E].view(B, T, H, 64).permute(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(-1, -2)
+    if pad is not None:
+        s = s.masked_fill(pad[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, -1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * T, E), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,T,H,lens", [
+    (2, 29, 2, None),
+    (3, 200, 2, [200, 131, 64]),     # one sequence whose last key tiles are all padding
+    (2, 512, 12, [512, 300]),
+    (1, 129, 1, [70]),
+])
+def test_attention_backward(dtype, B, T, H, lens):
+    E, M = H * 64, B * T
+    qkv = _rand(M, 3 * E, seed=31, scale=0.7)
+    qkv[:, :E] *= 0.35
+    d_out = _rand(M, E, seed=32)
+    pad = None
+    if lens is not None:
+        pad = torch.arange(T)[None, :] >= torch.tensor(lens)[:, None]
+    if dtype == torch.bfloat16:
+        qkv, d_out = _bf(qkv), _bf(d_out)
+    with torch.enable_grad():
+        x = qkv.clone().requires_grad_(True)
+        ref_out, ref_lse = _ref_attention(x, B, T, H, pad)
+        ref_out.backward(d_out)
+    words = None
+    if pad is not None:
+        words = ops.key_mask_words(pad.to(DEV, torch.uint8).contiguous(), B, T)
+    qd = qkv.to(DEV, dtype)
+    out, lse = ops.attention_train(qd, B, T, H, words)
+    np.testing.assert_allclose(lse.cpu().numpy(), ref_lse.detach().numpy(), rtol=1e-2 if dtype == torch.bfloat16
+                               else 1e-5, atol=2e-2 if dtype == torch.bfloat16 else 1e-5)
+    # the backward is fed the reference forward output so that its error is measured alone
+    got = ops.attention_bwd(qd, ref_out.detach().to(DEV, dtype), d_out.to(DEV, dtype), lse, B, T, H, words)
+    got = got.float().cpu()
+    ref = x.grad
+    for name, sl in (("dq", slice(0, E)), ("dk", slice(E, 2 * E)), ("dv", slice(2 * E, 3 * E))):
+        g, r = got[:, sl], ref[:, sl]
+        err = float((g - r).abs().max()) / max(float(r.abs().max()), 1e-6)
+        assert err < (2e-2 if dtype == torch.bfloat16 else 2e-5), (name, err)
+    if pad is not None:
+        assert float(got[:, E:][pad.reshape(-1)].abs().max()) == 0.0   # padded keys get no gradient

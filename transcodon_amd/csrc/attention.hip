@@ -23,6 +23,7 @@ struct AttnParams {
     const char *qkv;
     const uint64_t *words;
     char *out;
+    float *lse;   // optional [B,H,T]: natural-log sum of exp of each query's scores (for backward)
     long ldq_bytes, ldo_bytes;
     int B, T, H, E;
     int nw;       // validity words per sequence = ceil(T/64)
@@ -205,6 +206,9 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
     // ---- epilogue: normalise, stage through the wave's LDS rows, store 16 B per lane ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (p.lse && h2 == 0 && q0 + ql < p.T)
+        p.lse[((long)b * p.H + h) * p.T + q0 + ql] =
+            l_tot > 0.f ? (m_run + __log2f(l_tot)) * 0.69314718055994531f : INFINITY;
     char *ost = smem + 2 * KV_STAGE_BYTES + wid * OST_WAVE_BYTES;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -303,6 +307,7 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
     }
     if (q_ok) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        if (p.lse) p.lse[((long)b * p.H + h) * p.T + qi] = l_run > 0.f ? m_run + logf(l_run) : INFINITY;
         float *dst = reinterpret_cast<float *>(p.out + (row_base + qi) * p.ldo_bytes) + h * 64;
 #pragma unroll
         for (int d = 0; d < 64; d += 4)
@@ -343,8 +348,22 @@ __global__ __launch_bounds__(256) void scores_kernel(const T *__restrict__ qkv, 
 
 }  // namespace
 
+static int attn_fwd_impl(int dtype, const void *qkv, int ldq, const uint64_t *key_words, void *out, float *lse,
+                         int B, int T, int H, int D, void *stream);
+
 extern "C" int tc_attn_fwd(int dtype, const void *qkv, int ldq, const uint64_t *key_words,
                            void *out, int B, int T, int H, int D, void *stream) {
+    return attn_fwd_impl(dtype, qkv, ldq, key_words, out, nullptr, B, T, H, D, stream);
+}
+
+extern "C" int tc_attn_fwd_train(int dtype, const void *qkv, int ldq, const uint64_t *key_words, void *out,
+                                 float *lse, int B, int T, int H, int D, void *stream) {
+    TC_REQUIRE(lse != nullptr, "tc_attn_fwd_train: lse is required");
+    return attn_fwd_impl(dtype, qkv, ldq, key_words, out, lse, B, T, H, D, stream);
+}
+
+static int attn_fwd_impl(int dtype, const void *qkv, int ldq, const uint64_t *key_words, void *out, float *lse,
+                         int B, int T, int H, int D, void *stream) {
     TC_REQUIRE(dtype == TC_BF16 || dtype == TC_F32, "tc_attn_fwd: bad dtype %d", dtype);
     TC_REQUIRE(qkv && out, "tc_attn_fwd: null operand");
     TC_REQUIRE(D == 64, "tc_attn_fwd: head_dim %d unsupported (only 64)", D);
@@ -357,6 +376,7 @@ extern "C" int tc_attn_fwd(int dtype, const void *qkv, int ldq, const uint64_t *
     p.qkv = static_cast<const char *>(qkv);
     p.words = key_words;
     p.out = static_cast<char *>(out);
+    p.lse = lse;
     p.ldq_bytes = (long)ldq * esz;
     p.ldo_bytes = (long)E * esz;
     p.B = B; p.T = T; p.H = H; p.E = E;

@@ -1,0 +1,674 @@
+// Backward of the fused multi-head self-attention (head_dim 64, gfx950).
+//
+// With P = softmax(S), S = Q K^T (+ -inf at padded keys), O = P V and the incoming dO:
+//   delta[q] = sum_d dO[q,d] O[q,d]            (= sum_k P[q,k] dP[q,k])
+//   dP = dO V^T,  dS = P o (dP - delta),  dQ = dS K,  dK = dS^T Q,  dV = P^T dO.
+// P is rebuilt from the forward's per-query log-sum-exp: P = exp(S - lse).
+//
+// bf16: two MFMA kernels, neither of which needs atomics.
+//   dQ kernel  -- same shape as the forward: a workgroup owns 128 queries (32 per wave, query
+//     on the lane), streams 64-key K/V tiles through LDS and accumulates dQ^T = K^T dS^T.
+//   dK/dV kernel -- a workgroup owns 128 keys (32 per wave, key on the lane), streams 64-query
+//     tiles of Q, dO, lse and delta through LDS and accumulates dK^T = Q^T dS, dV^T = dO^T P.
+// Operands that are read both by rows (A operand of the S / dP products) and transposed
+// (A operand of the gradient products, via ds_read_b64_tr_b16) are staged twice with the
+// swizzle that suits each read pattern.
+//
+// f32 (exactness path): VALU kernels, one query (dQ) or one key (dK/dV) per lane.
+#include "common.h"
+
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr int TILE_BYTES = 64 * 128;   // 64 rows x 64 bf16
+constexpr int OST_LD = 144;
+constexpr int OST_WAVE_BYTES = 32 * OST_LD;
+
+struct BwdParams {
+    const char *qkv;
+    const uint64_t *words;
+    const char *out;      // forward output O [B*T, E]
+    const char *dout;     // dO [B*T, E]
+    const float *lse;     // [B,H,T]
+    float *delta;         // [B,H,T]
+    char *dqkv;           // [B*T, ldg]: dQ | dK | dV
+    long ldq_bytes, ldo_bytes, ldg_bytes;
+    int B, T, H, E;
+    int nw;               // validity words per sequence
+    int nblk;             // 128-row blocks per (b,h)
+};
+
+__device__ __forceinline__ int swz_row(int row) { return (row >> 1) & 7; }         // row reads
+__device__ __forceinline__ int swz_tr(int row) { return ((row >> 1) & 1) << 2; }   // transposed reads
+
+__device__ __forceinline__ uint64_t key_word(const BwdParams &p, int b, int kt) {
+    const int rem = p.T - kt * 64;
+    const uint64_t in_range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+    return p.words ? (p.words[(long)b * p.nw + kt] & in_range) : in_range;
+}
+
+// ------------------------------------------------------------------------------------------
+// delta[b,h,t] = sum_d dO * O ; 8 lanes per (row, head), 8 elements per lane
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void delta_kernel(const T *__restrict__ o, const T *__restrict__ d_o,
+                                                    float *__restrict__ delta, long rows, int Tn, int H) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long grp = gid >> 3;                 // (row, head)
+    const int part = (int)(gid & 7);
+    const long total = rows * H;
+    const long g = grp < total ? grp : total - 1;
+    const long row = g / H;
+    const int h = (int)(g % H);
+    const long off = row * (long)H * 64 + h * 64 + part * 8;
+    float acc = 0.f;
+    if constexpr (sizeof(T) == 2) {
+        const u32x4 a = *reinterpret_cast<const u32x4 *>(o + off);
+        const u32x4 c = *reinterpret_cast<const u32x4 *>(d_o + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            acc += tc_bf16_lo(a[i]) * tc_bf16_lo(c[i]) + tc_bf16_hi(a[i]) * tc_bf16_hi(c[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(o + off + 4 * i);
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(d_o + off + 4 * i);
+            acc += a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
+        }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (part == 0 && grp < total) {
+        const long b = row / Tn, t = row % Tn;
+        delta[(b * H + h) * Tn + t] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 dQ
+// ------------------------------------------------------------------------------------------
+constexpr int DQ_STAGE_BYTES = 3 * TILE_BYTES;                       // K rows, K for tr reads, V rows
+constexpr int DQ_LDS_BYTES = 2 * DQ_STAGE_BYTES + 4 * OST_WAVE_BYTES;
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int id = tc_xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = id % p.nblk;
+    const int bh = id / p.nblk;
+    const int h = bh % p.H, b = bh / p.H;
+    const int ql = lane & 31, h2 = lane >> 5;
+    const int q0 = qb * 128 + wid * 32;
+    const long row_base = (long)b * p.T;
+
+    int nkt = p.nw;
+    while (nkt > 0 && key_word(p, b, nkt - 1) == 0ull) --nkt;
+
+    // Q and dO fragments (B operands) and the query's lse / delta
+    bf16x8 qf[4], dof[4];
+    float lse2, dlt;
+    {
+        int qr = q0 + ql;
+        const bool ok = qr < p.T;
+        qr = ok ? qr : p.T - 1;
+        const char *qs = p.qkv + (row_base + qr) * p.ldq_bytes + (long)h * 128 + h2 * 16;
+        const char *ds = p.dout + (row_base + qr) * p.ldo_bytes + (long)h * 128 + h2 * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8 *>(qs + ks * 32);
+            dof[ks] = *reinterpret_cast<const bf16x8 *>(ds + ks * 32);
+        }
+        const long si = ((long)b * p.H + h) * p.T + qr;
+        lse2 = ok ? p.lse[si] * kLog2e : INFINITY;
+        dlt = p.delta[si];
+    }
+
+    const int srow = lane >> 3;
+    long src_kr[2], src_kt[2], src_vr[2];
+    int s_row[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wid * 2 + i) * 8 + srow;
+        s_row[i] = r;
+        src_kr[i] = (long)(p.E + h * 64) * 2 + (((lane & 7) ^ swz_row(r)) << 4);
+        src_kt[i] = (long)(p.E + h * 64) * 2 + (((lane & 7) ^ swz_tr(r)) << 4);
+        src_vr[i] = (long)(2 * p.E + h * 64) * 2 + (((lane & 7) ^ swz_row(r)) << 4);
+    }
+    auto stage = [&](int buf, int kt) {
+        char *base = smem + buf * DQ_STAGE_BYTES + wid * 2 * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int key = kt * 64 + s_row[i];
+            key = key < p.T ? key : p.T - 1;
+            const char *rowp = p.qkv + (row_base + key) * p.ldq_bytes;
+            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(rowp + src_kr[i]), TC_LDS_PTR(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(rowp + src_kt[i]),
+                                             TC_LDS_PTR(base + TILE_BYTES + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(rowp + src_vr[i]),
+                                             TC_LDS_PTR(base + 2 * TILE_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+
+    int r_off[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int r = kb * 32 + ql;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) r_off[kb][ks] = r * 128 + (((2 * ks + h2) ^ swz_row(r)) << 4);
+    }
+    const int tq = (lane & 15) >> 2, tp = lane & 3, thalf = (lane >> 4) & 1;
+    auto t_off = [&](int db, int row) {
+        const int c = 4 * db + 2 * thalf + (tp >> 1);
+        return row * 128 + ((c ^ swz_tr(row)) << 4) + 8 * (tp & 1);
+    };
+
+    f32x16 acc_dq[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_dq[db][r] = 0.f;
+
+    if (nkt > 0) stage(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+        const char *sb = smem + (kt & 1) * DQ_STAGE_BYTES;
+
+        f32x16 acc_s[2], acc_p[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc_s[kb][r] = 0.f; acc_p[kb][r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(sb + r_off[kb][ks]);
+                acc_s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc_s[kb], 0, 0, 0);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(sb + 2 * TILE_BYTES + r_off[kb][ks]);
+                acc_p[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], acc_p[kb], 0, 0, 0);
+            }
+        }
+
+        const uint64_t word = key_word(p, b, kt);
+        const uint64_t wsh = word >> (4 * h2);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const uint32_t wk = (uint32_t)(wsh >> (32 * kb));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pr = __builtin_amdgcn_exp2f(acc_s[kb][r] * kLog2e - lse2);
+                if (word != ~0ull) {
+                    const int bit = (r & 3) + 8 * (r >> 2);
+                    pr = ((wk >> bit) & 1u) ? pr : 0.f;
+                }
+                acc_s[kb][r] = pr * (acc_p[kb][r] - dlt);
+            }
+        }
+
+        // dQ^T[d][query] += K^T . dS^T
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 df;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) df[j] = (__bf16)acc_s[kb][8 * s + j];
+                const int key0 = kb * 32 + 16 * s + 4 * h2 + tq;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4 *)(sb + TILE_BYTES + t_off(db, key0)));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4 *)(sb + TILE_BYTES + t_off(db, key0 + 8)));
+                    bf16x8 kf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { kf[j] = lo[j]; kf[4 + j] = hi[j]; }
+                    acc_dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, df, acc_dq[db], 0, 0, 0);
+                }
+            }
+    }
+
+    char *ost = smem + 2 * DQ_STAGE_BYTES + wid * OST_WAVE_BYTES;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2 w;
+            w[0] = tc_pack_bf16(acc_dq[db][4 * g], acc_dq[db][4 * g + 1]);
+            w[1] = tc_pack_bf16(acc_dq[db][4 * g + 2], acc_dq[db][4 * g + 3]);
+            const int d = 32 * db + 8 * g + 4 * h2;
+            *reinterpret_cast<u32x2 *>(ost + ql * OST_LD + d * 2) = w;
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3), c = lane & 7;
+        const u32x4 w = *reinterpret_cast<const u32x4 *>(ost + r * OST_LD + c * 16);
+        const int q = q0 + r;
+        if (q < p.T)
+            *reinterpret_cast<u32x4 *>(p.dqkv + (row_base + q) * p.ldg_bytes + (long)h * 128 + c * 16) = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 dK / dV
+// ------------------------------------------------------------------------------------------
+constexpr int DKV_STAGE_BYTES = 4 * TILE_BYTES + 512;   // Q rows, Q tr, dO rows, dO tr, lse[64], delta[64]
+constexpr int DKV_LDS_BYTES = 2 * DKV_STAGE_BYTES;      // output staging reuses the stage area
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int id = tc_xcd_remap(blockIdx.x, gridDim.x);
+    const int kblk = id % p.nblk;
+    const int bh = id / p.nblk;
+    const int h = bh % p.H, b = bh / p.H;
+    const int kl = lane & 31, h2 = lane >> 5;
+    const int k0 = kblk * 128 + wid * 32;
+    const long row_base = (long)b * p.T;
+    const long stat_base = ((long)b * p.H + h) * p.T;
+    const int nqt = (p.T + 63) / 64;
+
+    // K and V fragments (B operands, key on the lane) and the key's validity
+    bf16x8 kf[4], vf[4];
+    bool k_ok;
+    {
+        int kr = k0 + kl;
+        k_ok = kr < p.T;
+        kr = k_ok ? kr : p.T - 1;
+        k_ok = k_ok && ((key_word(p, b, kr >> 6) >> (kr & 63)) & 1ull);
+        const char *ks_ = p.qkv + (row_base + kr) * p.ldq_bytes + (long)(p.E + h * 64) * 2 + h2 * 16;
+        const char *vs_ = ks_ + (long)p.E * 2;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8 *>(ks_ + ks * 32);
+            vf[ks] = *reinterpret_cast<const bf16x8 *>(vs_ + ks * 32);
+        }
+    }
+
+    const int srow = lane >> 3;
+    int s_row[2], c_row[2], c_tr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wid * 2 + i) * 8 + srow;
+        s_row[i] = r;
+        c_row[i] = h * 128 + (((lane & 7) ^ swz_row(r)) << 4);
+        c_tr[i] = h * 128 + (((lane & 7) ^ swz_tr(r)) << 4);
+    }
+    auto stage = [&](int buf, int qt) {
+        char *stg = smem + buf * DKV_STAGE_BYTES;
+        char *base = stg + wid * 2 * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int q = qt * 64 + s_row[i];
+            q = q < p.T ? q : p.T - 1;
+            const char *qrow = p.qkv + (row_base + q) * p.ldq_bytes;
+            const char *drow = p.dout + (row_base + q) * p.ldo_bytes;
+            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(qrow + c_row[i]), TC_LDS_PTR(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(qrow + c_tr[i]),
+                                             TC_LDS_PTR(base + TILE_BYTES + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(drow + c_row[i]),
+                                             TC_LDS_PTR(base + 2 * TILE_BYTES + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(drow + c_tr[i]),
+                                             TC_LDS_PTR(base + 3 * TILE_BYTES + i * 1024), 16, 0, 0);
+        }
+        if (wid < 2) {      // wave 0: lse, wave 1: delta (one float per lane)
+            int q = qt * 64 + lane;
+            q = q < p.T ? q : p.T - 1;
+            const float *src = (wid == 0 ? p.lse : p.delta) + stat_base + q;
+            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(src), TC_LDS_PTR(stg + 4 * TILE_BYTES + wid * 256), 4, 0,
+                                             0);
+        }
+    };
+
+    int r_off[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int r = qb * 32 + kl;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) r_off[qb][ks] = r * 128 + (((2 * ks + h2) ^ swz_row(r)) << 4);
+    }
+    const int tq = (lane & 15) >> 2, tp = lane & 3, thalf = (lane >> 4) & 1;
+    auto t_off = [&](int db, int row) {
+        const int c = 4 * db + 2 * thalf + (tp >> 1);
+        return row * 128 + ((c ^ swz_tr(row)) << 4) + 8 * (tp & 1);
+    };
+
+    f32x16 acc_dk[2], acc_dv[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_dk[db][r] = 0.f; acc_dv[db][r] = 0.f; }
+
+    stage(0, 0);
+    for (int qt = 0; qt < nqt; ++qt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (qt + 1 < nqt) stage((qt + 1) & 1, qt + 1);
+        const char *sb = smem + (qt & 1) * DKV_STAGE_BYTES;
+        const float *lse_s = reinterpret_cast<const float *>(sb + 4 * TILE_BYTES);
+        const float *dlt_s = lse_s + 64;
+        const bool ragged = qt * 64 + 64 > p.T;
+
+        // S[query][key], dP[query][key]
+        f32x16 acc_s[2], acc_p[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc_s[qb][r] = 0.f; acc_p[qb][r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 qa = *reinterpret_cast<const bf16x8 *>(sb + r_off[qb][ks]);
+                acc_s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], acc_s[qb], 0, 0, 0);
+                const bf16x8 da = *reinterpret_cast<const bf16x8 *>(sb + 2 * TILE_BYTES + r_off[qb][ks]);
+                acc_p[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], acc_p[qb], 0, 0, 0);
+            }
+        }
+
+        // P and dS; keep P in acc_s and dS in acc_p
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int qi = 32 * qb + 8 * g + 4 * h2;
+                const f32x4 l4 = *reinterpret_cast<const f32x4 *>(lse_s + qi);
+                const f32x4 d4 = *reinterpret_cast<const f32x4 *>(dlt_s + qi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j;
+                    float pr = __builtin_amdgcn_exp2f((acc_s[qb][r] - l4[j]) * kLog2e);
+                    bool ok = k_ok;
+                    if (ragged) ok = ok && (qt * 64 + qi + j < p.T);
+                    pr = ok ? pr : 0.f;
+                    acc_s[qb][r] = pr;
+                    acc_p[qb][r] = pr * (acc_p[qb][r] - d4[j]);
+                }
+            }
+
+        // dV^T[d][key] += dO^T . P ;  dK^T[d][key] += Q^T . dS
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pf, df;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pf[j] = (__bf16)acc_s[qb][8 * s + j];
+                    df[j] = (__bf16)acc_p[qb][8 * s + j];
+                }
+                const int row0 = qb * 32 + 16 * s + 4 * h2 + tq;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const int o_lo = t_off(db, row0), o_hi = t_off(db, row0 + 8);
+                    const bf16x4 dlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4 *)(sb + 3 * TILE_BYTES + o_lo));
+                    const bf16x4 dhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4 *)(sb + 3 * TILE_BYTES + o_hi));
+                    const bf16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4 *)(sb + TILE_BYTES + o_lo));
+                    const bf16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4 *)(sb + TILE_BYTES + o_hi));
+                    bf16x8 da, qa;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { da[j] = dlo[j]; da[4 + j] = dhi[j]; qa[j] = qlo[j]; qa[4 + j] = qhi[j]; }
+                    acc_dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, pf, acc_dv[db], 0, 0, 0);
+                    acc_dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, df, acc_dk[db], 0, 0, 0);
+                }
+            }
+    }
+
+    // ---- epilogue: dK then dV through the wave's staging rows (stage area is free now) ----
+    __syncthreads();
+    char *ost = smem + wid * OST_WAVE_BYTES;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const f32x16 *acc = which == 0 ? acc_dk : acc_dv;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w;
+                w[0] = tc_pack_bf16(acc[db][4 * g], acc[db][4 * g + 1]);
+                w[1] = tc_pack_bf16(acc[db][4 * g + 2], acc[db][4 * g + 3]);
+                const int d = 32 * db + 8 * g + 4 * h2;
+                *reinterpret_cast<u32x2 *>(ost + kl * OST_LD + d * 2) = w;
+            }
+        __builtin_amdgcn_wave_barrier();
+        const long col = (long)((which + 1) * p.E + h * 64) * 2;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = it * 8 + (lane >> 3), c = lane & 7;
+            const u32x4 w = *reinterpret_cast<const u32x4 *>(ost + r * OST_LD + c * 16);
+            const int k = k0 + r;
+            if (k < p.T) *reinterpret_cast<u32x4 *>(p.dqkv + (row_base + k) * p.ldg_bytes + col + c * 16) = w;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// f32 VALU kernels
+// ------------------------------------------------------------------------------------------
+constexpr int F32_RT = 32;   // rows per LDS tile
+
+__global__ __launch_bounds__(64) void attn_bwd_dq_f32_kernel(const BwdParams p) {
+    __shared__ __attribute__((aligned(16))) float ks[F32_RT][64];
+    __shared__ __attribute__((aligned(16))) float vs[F32_RT][64];
+    const int lane = threadIdx.x;
+    const int qb = blockIdx.x % p.nblk;
+    const int bh = blockIdx.x / p.nblk;
+    const int h = bh % p.H, b = bh / p.H;
+    const long row_base = (long)b * p.T;
+    int qi = qb * 64 + lane;
+    const bool q_ok = qi < p.T;
+    qi = q_ok ? qi : p.T - 1;
+
+    float q[64], g[64], dq[64];
+    {
+        const float *qs = reinterpret_cast<const float *>(p.qkv + (row_base + qi) * p.ldq_bytes) + h * 64;
+        const float *gs = reinterpret_cast<const float *>(p.dout + (row_base + qi) * p.ldo_bytes) + h * 64;
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(qs + d);
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(gs + d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { q[d + j] = a[j]; g[d + j] = c[j]; dq[d + j] = 0.f; }
+        }
+    }
+    const long si = ((long)b * p.H + h) * p.T + qi;
+    const float lse = p.lse[si], dlt = p.delta[si];
+
+    for (int k0 = 0; k0 < p.T; k0 += F32_RT) {
+        const uint64_t word = key_word(p, b, k0 >> 6);
+        const uint32_t bits = (uint32_t)(word >> (k0 & 63));
+        if (bits == 0u) continue;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = i * 64 + lane;
+            const int r = idx >> 4, c4 = idx & 15;
+            int key = k0 + r;
+            key = key < p.T ? key : p.T - 1;
+            const float *rowp = reinterpret_cast<const float *>(p.qkv + (row_base + key) * p.ldq_bytes);
+            *reinterpret_cast<f32x4 *>(&ks[r][c4 * 4]) = *reinterpret_cast<const f32x4 *>(rowp + p.E + h * 64 + c4 * 4);
+            *reinterpret_cast<f32x4 *>(&vs[r][c4 * 4]) =
+                *reinterpret_cast<const f32x4 *>(rowp + 2 * p.E + h * 64 + c4 * 4);
+        }
+        __syncthreads();
+        for (int j = 0; j < F32_RT; ++j) {
+            if (!((bits >> j) & 1u)) continue;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) {
+                s = fmaf(q[d], ks[j][d], s);
+                dp = fmaf(g[d], vs[j][d], dp);
+            }
+            const float ds = expf(s - lse) * (dp - dlt);
+#pragma unroll
+            for (int d = 0; d < 64; ++d) dq[d] = fmaf(ds, ks[j][d], dq[d]);
+        }
+    }
+    if (q_ok) {
+        float *dst = reinterpret_cast<float *>(p.dqkv + (row_base + qi) * p.ldg_bytes) + h * 64;
+#pragma unroll
+        for (int d = 0; d < 64; d += 4)
+            *reinterpret_cast<f32x4 *>(dst + d) = f32x4{dq[d], dq[d + 1], dq[d + 2], dq[d + 3]};
+    }
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_dkv_f32_kernel(const BwdParams p) {
+    __shared__ __attribute__((aligned(16))) float qs[F32_RT][64];
+    __shared__ __attribute__((aligned(16))) float gs[F32_RT][64];
+    __shared__ float lse_s[F32_RT], dlt_s[F32_RT];
+    const int lane = threadIdx.x;
+    const int kb = blockIdx.x % p.nblk;
+    const int bh = blockIdx.x / p.nblk;
+    const int h = bh % p.H, b = bh / p.H;
+    const long row_base = (long)b * p.T;
+    const long stat_base = ((long)b * p.H + h) * p.T;
+    int ki = kb * 64 + lane;
+    const bool in_range = ki < p.T;
+    ki = in_range ? ki : p.T - 1;
+    const bool k_ok = in_range && ((key_word(p, b, ki >> 6) >> (ki & 63)) & 1ull);
+
+    float k[64], v[64], dk[64], dv[64];
+    {
+        const float *rowp = reinterpret_cast<const float *>(p.qkv + (row_base + ki) * p.ldq_bytes);
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(rowp + p.E + h * 64 + d);
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(rowp + 2 * p.E + h * 64 + d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { k[d + j] = a[j]; v[d + j] = c[j]; dk[d + j] = 0.f; dv[d + j] = 0.f; }
+        }
+    }
+
+    for (int q0 = 0; q0 < p.T; q0 += F32_RT) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = i * 64 + lane;
+            const int r = idx >> 4, c4 = idx & 15;
+            int qi = q0 + r;
+            qi = qi < p.T ? qi : p.T - 1;
+            *reinterpret_cast<f32x4 *>(&qs[r][c4 * 4]) = *reinterpret_cast<const f32x4 *>(
+                reinterpret_cast<const float *>(p.qkv + (row_base + qi) * p.ldq_bytes) + h * 64 + c4 * 4);
+            *reinterpret_cast<f32x4 *>(&gs[r][c4 * 4]) = *reinterpret_cast<const f32x4 *>(
+                reinterpret_cast<const float *>(p.dout + (row_base + qi) * p.ldo_bytes) + h * 64 + c4 * 4);
+        }
+        if (lane < F32_RT) {
+            const int qi = q0 + lane;
+            lse_s[lane] = qi < p.T ? p.lse[stat_base + qi] : INFINITY;
+            dlt_s[lane] = qi < p.T ? p.delta[stat_base + qi] : 0.f;
+        }
+        __syncthreads();
+        for (int j = 0; j < F32_RT; ++j) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) {
+                s = fmaf(qs[j][d], k[d], s);
+                dp = fmaf(gs[j][d], v[d], dp);
+            }
+            const float pr = k_ok ? expf(s - lse_s[j]) : 0.f;
+            const float ds = pr * (dp - dlt_s[j]);
+#pragma unroll
+            for (int d = 0; d < 64; ++d) {
+                dv[d] = fmaf(pr, gs[j][d], dv[d]);
+                dk[d] = fmaf(ds, qs[j][d], dk[d]);
+            }
+        }
+    }
+    if (in_range) {
+        float *rowp = reinterpret_cast<float *>(p.dqkv + (row_base + ki) * p.ldg_bytes);
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            *reinterpret_cast<f32x4 *>(rowp + p.E + h * 64 + d) = f32x4{dk[d], dk[d + 1], dk[d + 2], dk[d + 3]};
+            *reinterpret_cast<f32x4 *>(rowp + 2 * p.E + h * 64 + d) = f32x4{dv[d], dv[d + 1], dv[d + 2], dv[d + 3]};
+        }
+    }
+}
+
+int set_lds_attr(const void *fn, int bytes, const char *what) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        tc_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+        return TC_ELAUNCH;
+    }
+    return TC_OK;
+}
+
+}  // namespace
+
+extern "C" int tc_attn_bwd(int dtype, const void *qkv, int ldq, const uint64_t *key_words, const void *out,
+                           const void *d_out, const float *lse, float *delta, void *d_qkv, int ldg, int B, int T,
+                           int H, int D, void *stream) {
+    TC_REQUIRE(dtype == TC_BF16 || dtype == TC_F32, "tc_attn_bwd: bad dtype %d", dtype);
+    TC_REQUIRE(qkv && out && d_out && lse && delta && d_qkv, "tc_attn_bwd: null operand");
+    TC_REQUIRE(D == 64, "tc_attn_bwd: head_dim %d unsupported (only 64)", D);
+    TC_REQUIRE(B > 0 && T > 0 && H > 0, "tc_attn_bwd: bad shape B=%d T=%d H=%d", B, T, H);
+    const int E = H * D;
+    const int esz = dtype == TC_BF16 ? 2 : 4;
+    TC_REQUIRE(ldq >= 3 * E && (ldq * esz) % 16 == 0, "tc_attn_bwd: ldq=%d too small or misaligned", ldq);
+    TC_REQUIRE(ldg >= 3 * E && (ldg * esz) % 16 == 0, "tc_attn_bwd: ldg=%d too small or misaligned", ldg);
+    TC_REQUIRE(tc_aligned16(qkv) && tc_aligned16(out) && tc_aligned16(d_out) && tc_aligned16(d_qkv),
+               "tc_attn_bwd: operands must be 16-byte aligned");
+    BwdParams p{};
+    p.qkv = static_cast<const char *>(qkv);
+    p.words = key_words;
+    p.out = static_cast<const char *>(out);
+    p.dout = static_cast<const char *>(d_out);
+    p.lse = lse;
+    p.delta = delta;
+    p.dqkv = static_cast<char *>(d_qkv);
+    p.ldq_bytes = (long)ldq * esz;
+    p.ldo_bytes = (long)E * esz;
+    p.ldg_bytes = (long)ldg * esz;
+    p.B = B; p.T = T; p.H = H; p.E = E;
+    p.nw = (T + 63) / 64;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // dP, S (twice), dQ, dK, dV products: 7 x 2 B H T^2 D
+    TcProfScope prof(TC_PROF_ATTN, s, 14.0 * (double)B * H * (double)T * (double)T * D);
+
+    const long rows = (long)B * T;
+    const long dthreads = rows * H * 8;
+    const long dgrid = (dthreads + 255) / 256;
+    TC_REQUIRE(dgrid < (1L << 31), "tc_attn_bwd: grid too large");
+    if (dtype == TC_BF16)
+        hipLaunchKernelGGL(delta_kernel<uint16_t>, dim3((unsigned)dgrid), dim3(256), 0, s,
+                           static_cast<const uint16_t *>(out), static_cast<const uint16_t *>(d_out), delta, rows, T,
+                           H);
+    else
+        hipLaunchKernelGGL(delta_kernel<float>, dim3((unsigned)dgrid), dim3(256), 0, s,
+                           static_cast<const float *>(out), static_cast<const float *>(d_out), delta, rows, T, H);
+    TC_CHECK_LAUNCH("tc_attn_bwd(delta)");
+
+    if (dtype == TC_BF16) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            int rc = set_lds_attr(reinterpret_cast<const void *>(attn_bwd_dq_bf16_kernel), DQ_LDS_BYTES, "tc_attn_bwd");
+            if (rc != TC_OK) return rc;
+            rc = set_lds_attr(reinterpret_cast<const void *>(attn_bwd_dkv_bf16_kernel), DKV_LDS_BYTES, "tc_attn_bwd");
+            if (rc != TC_OK) return rc;
+            attr_set = true;
+        }
+        p.nblk = (T + 127) / 128;
+        const long grid = (long)p.nblk * H * B;
+        TC_REQUIRE(grid < (1L << 31), "tc_attn_bwd: grid too large");
+        hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3((unsigned)grid), dim3(256), DQ_LDS_BYTES, s, p);
+        TC_CHECK_LAUNCH("tc_attn_bwd(dq)");
+        hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3((unsigned)grid), dim3(256), DKV_LDS_BYTES, s, p);
+        TC_CHECK_LAUNCH("tc_attn_bwd(dkv)");
+    } else {
+        p.nblk = (T + 63) / 64;
+        const long grid = (long)p.nblk * H * B;
+        TC_REQUIRE(grid < (1L << 31), "tc_attn_bwd: grid too large");
+        hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, dim3((unsigned)grid), dim3(64), 0, s, p);
+        TC_CHECK_LAUNCH("tc_attn_bwd(dq)");
+        hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, dim3((unsigned)grid), dim3(64), 0, s, p);
+        TC_CHECK_LAUNCH("tc_attn_bwd(dkv)");
+    }
+    return TC_OK;
+}

@@ -252,3 +252,29 @@ def rope_bwd(dqkv, cos, sin, T, E, head_dim, q_scale):
     check(_lib.load().tc_rope_bwd(_dt(dqkv), _p(dqkv), dqkv.stride(0), _p(cos), _p(sin), dqkv.shape[0], T, E,
                                   head_dim, q_scale, _stream()), "tc_rope_bwd")
     return dqkv
+
+
+def attention_train(qkv, B, T, H, key_words=None):
+    """Forward that also returns lse f32 [B,H,T] for attention_bwd (tc_attn_fwd_train)."""
+    _dev(qkv, key_words)
+    E = H * 64
+    out = torch.empty(B * T, E, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    check(_lib.load().tc_attn_fwd_train(_dt(qkv), _p(qkv), qkv.stride(0), _p(key_words), _p(out), _p(lse),
+                                        B, T, H, 64, _stream()), "tc_attn_fwd_train")
+    return out, lse
+
+
+def attention_bwd(qkv, out, d_out, lse, B, T, H, key_words=None):
+    """Gradient of attention() with respect to its qkv input (tc_attn_bwd) -> d_qkv like qkv."""
+    _dev(qkv, out, d_out, lse, key_words)
+    E = H * 64
+    if out.shape != (B * T, E) or d_out.shape != (B * T, E) or not out.is_contiguous() or not d_out.is_contiguous():
+        raise ValueError("attention_bwd: out and d_out must be contiguous [B*T, E]")
+    if d_out.dtype != qkv.dtype or out.dtype != qkv.dtype:
+        raise ValueError("attention_bwd: out/d_out dtype must match qkv")
+    d_qkv = torch.empty(B * T, 3 * E, dtype=qkv.dtype, device=qkv.device)
+    delta = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    check(_lib.load().tc_attn_bwd(_dt(qkv), _p(qkv), qkv.stride(0), _p(key_words), _p(out), _p(d_out), _p(lse),
+                                  _p(delta), _p(d_qkv), d_qkv.stride(0), B, T, H, 64, _stream()), "tc_attn_bwd")
+    return d_qkv
