@@ -334,6 +334,69 @@ int tc_prof_enable(int enabled);
 int tc_prof_reset(void);
 int tc_prof_collect(int kind, int64_t *launches, double *ms_total, double *work_total);
 
+/* ---- training step (pretraining.py:94-134: forward, loss, autograd backward, AdamW) ------ */
+
+/*
+ * Gradient buffers, f32, shaped like the weights of tc_layer_weights / tc_encoder_desc (the
+ * packed [3E,E] q/k/v matrix and [2E,E] head matrix included).  Every buffer is ACCUMULATED
+ * into: zero them before the first micro-batch of an optimiser step.
+ */
+typedef struct tc_layer_grads {
+    float *ln1_g, *ln1_b, *w_qkv, *b_qkv, *w_o, *b_o, *ln2_g, *ln2_b, *w_fc1, *b_fc1, *w_fc2, *b_fc2;
+} tc_layer_grads;
+
+typedef struct tc_encoder_grads {
+    float *tok_table;       /* embed_tokens.weight: embedding + tied LM projection */
+    float *species_table;
+    tc_layer_grads *layers;
+    float *lnf_g, *lnf_b;
+    float *w_heads, *b_heads;
+    float *lm_ln_g, *lm_ln_b, *lm_bias;
+    float *st_ln_g, *st_ln_b, *st_w;
+    float *st_bias;         /* gradient of both structure_linear.out_proj.bias and .bias */
+} tc_encoder_grads;
+
+/* Bytes of workspace for tc_encoder_forward_train + tc_encoder_backward on a [B,T] batch. */
+size_t tc_train_workspace_bytes(const tc_encoder_desc *desc, int B, int T);
+
+/*
+ * tc_encoder_forward (transcodon/model.py:175-259) that keeps the activations the backward
+ * needs in `workspace`, which the caller must leave untouched until tc_encoder_backward has
+ * been enqueued.  Both heads are always evaluated.
+ */
+int tc_encoder_forward_train(const tc_encoder_desc *desc, const int32_t *tokens, const int32_t *species,
+                             int B, int T, float *logits, float *struct_logits, int32_t *bad_index,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Gradients of every parameter given d(loss)/d(logits) [B*T,vocab] and, optionally,
+ * d(loss)/d(struct_logits) [B*T,n_struct] (NULL when the structure term is absent): what
+ * loss.backward() produces in CodonModel.training_step (pretraining.py:94-134).
+ */
+int tc_encoder_backward(const tc_encoder_desc *desc, const tc_encoder_grads *grads, const int32_t *tokens,
+                        const int32_t *species, int B, int T, const float *dlogits,
+                        const float *dstruct_logits, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * The objective of pretraining.py:109-130 with its gradient:
+ *   loss = CE_mean(logits, labels; ignore -100)
+ *          + struct_weight * CE_mean(struct_logits, struct_labels; ignore -100)   if any struct label is set
+ * loss f32[1] (device).  dlogits / dstruct_logits (optional) receive d(upstream * loss)/d(logits).
+ * stats: 16 bytes of device scratch (sums and counts).  struct_* may all be NULL.
+ */
+int tc_mlm_loss(const float *logits, const int32_t *labels, const float *struct_logits,
+                const int32_t *struct_labels, float *loss, float *dlogits, float *dstruct_logits, float *stats,
+                float struct_weight, float upstream, int M, int V, int S, void *stream);
+
+/*
+ * One AdamW update over n contiguous f32 values, torch.optim.AdamW semantics (pretraining.py:64-70:
+ * decoupled weight decay on every parameter): p *= 1 - lr*wd; m, v moments of grad*grad_scale;
+ * p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).  step counts from 1.
+ */
+int tc_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

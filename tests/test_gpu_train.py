@@ -1,0 +1,178 @@
+"""Training step on the GPU (tc_encoder_forward_train / tc_encoder_backward / tc_mlm_loss /
+tc_adamw_step) against torch autograd of the CPU oracle on the same seeded weights.
+
+Stated tolerances (per parameter tensor, error relative to that tensor's largest gradient)
+  f32 path : <= 2e-4        bf16 path : <= 6e-2 and cosine similarity >= 0.995
+"""
+import numpy as np
+import pytest
+import torch
+
+import transcodon_amd as ta
+from oracle import transcodon_ref as O
+from oracle.weights import seeded_state_dict
+from transcodon_amd import train as TR
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model(cfg, sd, dtype):
+    args = ta.default_args(num_layers=cfg.num_layers, embed_dim=cfg.embed_dim,
+                           ffn_embed_dim=cfg.ffn_embed_dim, attention_heads=cfg.attention_heads,
+                           species_vocab_size=cfg.species_vocab_size)
+    m = ta.ProteinBertModel(args, ta.Alphabet.from_architecture("CodonModel"))
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).train().set_compute_dtype(dtype)
+
+
+def _batch(cfg, B, T, seed, pad_tail=(0,), struct=False):
+    rng = np.random.default_rng(seed)
+    tok = rng.integers(5, 9, (B, T))
+    tok[:, 0] = 0
+    labels = np.full((B, T), -100)
+    sel = rng.random((B, T)) < 0.25
+    labels[sel] = tok[sel]
+    tok[sel & (rng.random((B, T)) < 0.8)] = 9
+    for b, n in enumerate(pad_tail):
+        if n:
+            tok[b, T - n:] = 1
+            labels[b, T - n:] = -100
+    st = np.full((B, T), -100)
+    if struct:
+        st[:, 1:T // 2] = rng.integers(0, 3, (B, T // 2 - 1))
+        st[tok == 1] = -100
+    sp = rng.integers(0, cfg.species_vocab_size, (B,))
+    return (torch.from_numpy(tok), torch.from_numpy(sp), torch.from_numpy(labels), torch.from_numpy(st))
+
+
+def _oracle_grads(cfg, sd, tok, sp, labels, st):
+    with torch.enable_grad():
+        leaf = {k: v.clone().requires_grad_(v.is_floating_point() and "rope" not in k) for k, v in sd.items()}
+        out = O.forward(leaf, cfg, tok, sp, repr_layers=())
+        loss = O.mlm_loss(out["logits"], labels, out["struct_label_output"], st)
+        loss.backward()
+    return float(loss), {k: v.grad for k, v in leaf.items() if v.grad is not None}, out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("struct", [False, True])
+def test_tiny_gradients_match_oracle_autograd(dtype, struct):
+    cfg = O.TINY
+    sd = seeded_state_dict(cfg, 11, perturb=True)
+    tok, sp, labels, st = _batch(cfg, 3, 40, 5, pad_tail=(0, 7, 19), struct=struct)
+    ref_loss, ref, ref_out = _oracle_grads(cfg, sd, tok, sp, labels, st)
+    m = _model(cfg, sd, dtype)
+    out = m(tok.to(DEV), sp.to(DEV))
+    loss = TR.mlm_loss(out["logits"], labels.to(DEV), out["struct_label_output"], st.to(DEV))
+    loss.backward()
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+    assert abs(float(loss) - ref_loss) <= (1e-4 if dtype == torch.float32 else 3e-2), (float(loss), ref_loss)
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    missing = sorted(set(ref) - set(got) - {"lm_head.weight"})
+    assert not missing, missing
+    worst = {}
+    for k, r in ref.items():
+        if k == "lm_head.weight":
+            continue
+        g = got[k].float().cpu()
+        if k == "embed_tokens.weight" and "lm_head.weight" in ref:
+            r = r + ref["lm_head.weight"]
+        scale = max(float(r.abs().max()), 1e-8)
+        err = float((g - r).abs().max()) / scale
+        worst[k] = err
+        assert err <= tol, (k, err)
+        if dtype == torch.bfloat16 and r.numel() > 16:
+            cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-30))
+            assert cos >= 0.995, (k, cos)
+    if not struct:     # no structure labels: the structure head receives no gradient at all
+        assert all(p.grad is None or float(p.grad.abs().max()) == 0.0
+                   for k, p in m.named_parameters() if k.startswith("structure_linear"))
+
+
+def test_mlm_loss_matches_oracle():
+    rng = np.random.default_rng(3)
+    M = 999
+    logits = torch.from_numpy(rng.normal(size=(M, 10)).astype(np.float32))
+    slog = torch.from_numpy(rng.normal(size=(M, 3)).astype(np.float32))
+    labels = torch.from_numpy(np.where(rng.random(M) < 0.3, rng.integers(0, 10, M), -100))
+    sl = torch.from_numpy(np.where(rng.random(M) < 0.5, rng.integers(0, 3, M), -100))
+    for st in (sl, torch.full((M,), -100), None):
+        with torch.enable_grad():
+            a, b = logits.clone().requires_grad_(True), slog.clone().requires_grad_(True)
+            ref = O.mlm_loss(a, labels, b, st)
+            (ref * 1.7).backward()
+            x, y = logits.to(DEV).requires_grad_(True), slog.to(DEV).requires_grad_(True)
+            got = TR.mlm_loss(x, labels.to(DEV), y, None if st is None else st.to(DEV))
+            (got * 1.7).backward()
+        assert abs(float(got) - float(ref)) <= 1e-5
+        np.testing.assert_allclose(x.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-4, atol=1e-7)
+        if b.grad is not None:
+            np.testing.assert_allclose(y.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-7)
+        else:
+            assert y.grad is None
+
+
+def test_adamw_matches_torch():
+    n = 100003
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=g)
+    lin = torch.nn.Linear(1, 1)          # carrier module with one flat parameter
+    lin.weight = torch.nn.Parameter(p0.clone().to(DEV))
+    lin.bias = None
+    ref_p = torch.nn.Parameter(p0.clone())
+    ref_opt = torch.optim.AdamW([ref_p], lr=2e-4, weight_decay=0.1)
+    flat = TR.FlatParameters(lin)
+    opt = TR.AdamW(flat, lr=2e-4, weight_decay=0.1)
+    for step in range(5):
+        grad = torch.randn(n, generator=g) * (10.0 ** (step - 2))
+        factor = TR.warmup_cosine(step, 3, 10)
+        for group in ref_opt.param_groups:
+            group["lr"] = 2e-4 * factor
+        ref_p.grad = grad.clone()
+        ref_opt.step()
+        flat.zero_grad()
+        lin.weight.grad.copy_(grad.to(DEV))
+        opt.step(lr_factor=factor)
+        np.testing.assert_allclose(lin.weight.detach().cpu().numpy(), ref_p.detach().numpy(), rtol=2e-6, atol=1e-7)
+
+
+def test_schedule_matches_oracle():
+    for s in range(0, 60, 7):
+        assert TR.warmup_cosine(s, 10, 40) == O.warmup_cosine(s, 10, 40)
+
+
+def test_training_loop_reduces_loss_and_tracks_oracle():
+    """Three optimiser steps on the tiny model in f32, replayed with torch.optim.AdamW on the
+    oracle: the losses must agree step by step (this exercises weight repacking after updates)."""
+    cfg = O.TINY
+    sd = seeded_state_dict(cfg, 21, perturb=True)
+    m = _model(cfg, sd, torch.float32)
+    flat = TR.FlatParameters(m)
+    opt = TR.AdamW(flat, lr=1e-3, weight_decay=0.1)
+    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point() and "rope" not in k) for k, v in sd.items()}
+    ref_sd["lm_head.weight"] = ref_sd["embed_tokens.weight"]
+    used = None
+    losses, ref_losses = [], []
+    ref_opt = None
+    for step in range(3):
+        tok, sp, labels, st = _batch(cfg, 2, 24, 100 + step, pad_tail=(0, 5))
+        with torch.enable_grad():
+            out = O.forward(ref_sd, cfg, tok, sp, repr_layers=())
+            rl = O.mlm_loss(out["logits"], labels, out["struct_label_output"], st)
+            if ref_opt is None:
+                rl.backward()
+                used = [v for v in {id(v): v for v in ref_sd.values()}.values() if v.grad is not None]
+                ref_opt = torch.optim.AdamW(used, lr=1e-3, weight_decay=0.1)
+            else:
+                ref_opt.zero_grad()
+                rl.backward()
+            ref_opt.step()
+        ref_losses.append(float(rl))
+        flat.zero_grad()
+        o = m(tok.to(DEV), sp.to(DEV))
+        loss = TR.mlm_loss(o["logits"], labels.to(DEV), o["struct_label_output"], st.to(DEV))
+        loss.backward()
+        opt.step(exclude=TR.structure_head_parameters(m))
+        losses.append(float(loss))
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-4, atol=2e-4)

@@ -36,6 +36,22 @@ class EncoderDesc(C.Structure):
     )
 
 
+LAYER_GRAD_FIELDS = ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_g", "ln2_b",
+                     "w_fc1", "b_fc1", "w_fc2", "b_fc2")
+HEAD_GRAD_FIELDS = ("lnf_g", "lnf_b", "w_heads", "b_heads", "lm_ln_g", "lm_ln_b", "lm_bias",
+                    "st_ln_g", "st_ln_b", "st_w", "st_bias")
+
+
+class LayerGrads(C.Structure):
+    _fields_ = [(n, vp) for n in LAYER_GRAD_FIELDS]
+
+
+class EncoderGrads(C.Structure):
+    _fields_ = ([(n, vp) for n in ("tok_table", "species_table")]
+                + [("layers", C.POINTER(LayerGrads))]
+                + [(n, vp) for n in HEAD_GRAD_FIELDS])
+
+
 class HipLibraryError(RuntimeError):
     pass
 
@@ -75,6 +91,13 @@ _SIGNATURES = {
     "tc_encoder_forward": (C.c_int, [C.POINTER(EncoderDesc), vp, vp, C.c_int, C.c_int, vp, vp, vp,
                                      C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), vp, vp,
                                      C.c_size_t, vp]),
+    "tc_train_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc), C.c_int, C.c_int]),
+    "tc_encoder_forward_train": (C.c_int, [C.POINTER(EncoderDesc), vp, vp, C.c_int, C.c_int, vp, vp, vp, vp,
+                                           C.c_size_t, vp]),
+    "tc_encoder_backward": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderGrads), vp, vp, C.c_int, C.c_int,
+                                      vp, vp, vp, C.c_size_t, vp]),
+    "tc_mlm_loss": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, vp]),
+    "tc_adamw_step": (C.c_int, [vp, vp, vp, vp, C.c_long] + [C.c_float] * 5 + [C.c_int, C.c_float, vp]),
     "tc_prof_enable": (C.c_int, [C.c_int]),
     "tc_prof_reset": (C.c_int, []),
     "tc_prof_collect": (C.c_int, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double),
@@ -82,6 +105,9 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+# bumped by optimisers that update parameter memory without torch noticing; part of every
+# packed-weight cache key
+weights_epoch = [0]
 _lib = None
 
 

@@ -760,7 +760,8 @@ static int gemm_impl(int dtype, int epilogue, const void *A, int lda, const void
     TC_REQUIRE((lda * esz) % 16 == 0 && ldo % 8 == 0, "tc_gemm: leading dimensions must keep rows 16-byte aligned");
     TC_REQUIRE(tc_aligned16(A) && tc_aligned16(W) && tc_aligned16(out) && tc_aligned16(bias),
                "tc_gemm: operands must be 16-byte aligned");
-    TC_REQUIRE(bias || epilogue == TC_EPI_PLAIN_F32 || epilogue == TC_EPI_DGELU || epilogue == TC_EPI_BIAS_RESIDUAL,
+    TC_REQUIRE(bias || epilogue == TC_EPI_PLAIN_F32 || epilogue == TC_EPI_DGELU || epilogue == TC_EPI_BIAS_RESIDUAL ||
+                   epilogue == TC_EPI_BIAS,
                "tc_gemm: this epilogue needs a bias vector");
     TC_REQUIRE(splits >= 1 && splits <= 64, "tc_gemm: bad split count %d", splits);
     TC_REQUIRE(splits == 1 || epilogue == TC_EPI_PLAIN_F32, "tc_gemm: split-K needs the plain f32 epilogue");

@@ -323,6 +323,60 @@ __global__ __launch_bounds__(256) void rope_bwd_kernel(T *__restrict__ dqkv, lon
     p[1] = from_f32<T>((d1 * c - d0 * s) * sc);
 }
 
+// ---- masked-LM objective: combine the two cross-entropy sums, scale the logit gradients -------
+// stats: [0] = lm loss sum, [1] = struct loss sum (f32); counts: [0], [1] (int32)
+__global__ __launch_bounds__(256) void mlm_finalize_kernel(const float *__restrict__ stats,
+                                                           const int32_t *__restrict__ counts, float *loss,
+                                                           float *dl, long n_dl, float *ds, long n_ds,
+                                                           float struct_weight, float upstream) {
+    const int c0 = counts[0], c1 = counts[1];
+    const float s0 = c0 > 0 ? 1.0f / (float)c0 : 0.f;
+    const float s1 = c1 > 0 ? struct_weight / (float)c1 : 0.f;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        float v = c0 > 0 ? stats[0] * s0 : __builtin_nanf("");   // mean over zero rows is NaN in torch too
+        if (c1 > 0) v += stats[1] * s1;
+        loss[0] = v;
+    }
+    if (dl && i < n_dl) dl[i] *= s0 * upstream;
+    if (ds && i < n_ds) ds[i] *= s1 * upstream;
+}
+
+// ---- AdamW (decoupled weight decay), torch.optim.AdamW update order ----------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                    float *__restrict__ m, float *__restrict__ v, long n, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float bc1,
+                                                    float rsqrt_bc2, float grad_scale) {
+    const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    if (i4 + 4 <= n) {
+        f32x4 pp = *reinterpret_cast<f32x4 *>(p + i4);
+        f32x4 mm = *reinterpret_cast<f32x4 *>(m + i4);
+        f32x4 vv = *reinterpret_cast<f32x4 *>(v + i4);
+        const f32x4 gg = *reinterpret_cast<const f32x4 *>(g + i4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gr = gg[j] * grad_scale;
+            float x = pp[j] * (1.0f - lr * wd);
+            mm[j] = mm[j] + (gr - mm[j]) * (1.0f - beta1);
+            vv[j] = vv[j] * beta2 + gr * gr * (1.0f - beta2);
+            const float denom = sqrtf(vv[j]) * rsqrt_bc2 + eps;
+            pp[j] = x - (lr / bc1) * (mm[j] / denom);
+        }
+        *reinterpret_cast<f32x4 *>(p + i4) = pp;
+        *reinterpret_cast<f32x4 *>(m + i4) = mm;
+        *reinterpret_cast<f32x4 *>(v + i4) = vv;
+    } else {
+        for (long i = i4; i < n; ++i) {
+            const float gr = g[i] * grad_scale;
+            const float x = p[i] * (1.0f - lr * wd);
+            m[i] = m[i] + (gr - m[i]) * (1.0f - beta1);
+            v[i] = v[i] * beta2 + gr * gr * (1.0f - beta2);
+            p[i] = x - (lr / bc1) * (m[i] / (sqrtf(v[i]) * rsqrt_bc2 + eps));
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int tc_transpose_cast(int in_dtype, int out_dtype, const void *in, int ld_in, void *out_t, int ldt,
@@ -452,5 +506,48 @@ extern "C" int tc_rope_bwd(int dtype, void *dqkv, int ld, const float *rope_cos,
         hipLaunchKernelGGL(rope_bwd_kernel<uint16_t>, grid, block, 0, s, static_cast<uint16_t *>(dqkv), (long)ld,
                            rope_cos, rope_sin, M, T, E, head_dim, q_scale);
     TC_CHECK_LAUNCH("tc_rope_bwd");
+    return TC_OK;
+}
+
+extern "C" int tc_mlm_loss(const float *logits, const int32_t *labels, const float *struct_logits,
+                           const int32_t *struct_labels, float *loss, float *dlogits, float *dstruct_logits,
+                           float *stats, float struct_weight, float upstream, int M, int V, int S, void *stream) {
+    TC_REQUIRE(logits && labels && loss && stats, "tc_mlm_loss: null operand");
+    TC_REQUIRE((struct_logits != nullptr) == (struct_labels != nullptr), "tc_mlm_loss: struct logits and labels go together");
+    TC_REQUIRE(!dstruct_logits || struct_logits, "tc_mlm_loss: struct gradient without struct logits");
+    TC_REQUIRE(M > 0 && V > 0 && V <= 64 && (!struct_logits || (S > 0 && S <= 64)), "tc_mlm_loss: bad shape");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const hipError_t e = hipMemsetAsync(stats, 0, 16, s);
+    if (e != hipSuccess) {
+        tc_set_error("tc_mlm_loss: memset: %s", hipGetErrorString(e));
+        return TC_ELAUNCH;
+    }
+    int32_t *counts = reinterpret_cast<int32_t *>(stats + 2);
+    int rc = tc_ce_loss_fwd_bwd(logits, labels, stats, counts, dlogits, 1.0f, M, V, stream);
+    if (rc != TC_OK) return rc;
+    if (struct_logits) {
+        rc = tc_ce_loss_fwd_bwd(struct_logits, struct_labels, stats + 1, counts + 1, dstruct_logits, 1.0f, M, S, stream);
+        if (rc != TC_OK) return rc;
+    }
+    const long n_dl = dlogits ? (long)M * V : 0, n_ds = dstruct_logits ? (long)M * S : 0;
+    long n = n_dl > n_ds ? n_dl : n_ds;
+    if (n < 1) n = 1;
+    hipLaunchKernelGGL(mlm_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, stats, counts, loss,
+                       dlogits, n_dl, dstruct_logits, n_ds, struct_weight, upstream);
+    TC_CHECK_LAUNCH("tc_mlm_loss");
+    return TC_OK;
+}
+
+extern "C" int tc_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                             void *stream) {
+    TC_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "tc_adamw_step: bad arguments");
+    TC_REQUIRE(tc_aligned16(param) && tc_aligned16(grad) && tc_aligned16(exp_avg) && tc_aligned16(exp_avg_sq),
+               "tc_adamw_step: operands must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                       weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+    TC_CHECK_LAUNCH("tc_adamw_step");
     return TC_OK;
 }

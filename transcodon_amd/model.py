@@ -76,6 +76,8 @@ class ProteinBertModel(nn.Module):
         self.check_indices = True       # raise IndexError on out-of-range token / species ids
         self._pack = {}
         self._workspace = None
+        self._train_workspace = None
+        self._train_generation = 0
 
     @property
     def num_layers(self):
@@ -142,12 +144,13 @@ class ProteinBertModel(nn.Module):
         self._pack = {"key": key, "desc": d, "layers": layers, "keep": keep, "per_layer": per_layer}
         return self._pack
 
-    def _get_workspace(self, nbytes, device):
-        ws = self._workspace
+    def _get_workspace(self, nbytes, device, train=False):
+        attr = "_train_workspace" if train else "_workspace"
+        ws = getattr(self, attr)
         if ws is None or ws.numel() < nbytes or ws.device != device:
-            self._workspace = None
+            setattr(self, attr, None)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self._workspace = ws
+            setattr(self, attr, ws)
         return ws
 
     # -- forward ---------------------------------------------------------------------------
@@ -158,8 +161,9 @@ class ProteinBertModel(nn.Module):
                 "ProteinBertModel.forward runs on the MI355X kernels only: move the model and "
                 "its inputs to the GPU (there is no CPU fallback)")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "autograd through the HIP forward is not built yet: call under torch.no_grad()")
+            if need_head_weights:
+                raise NotImplementedError("need_head_weights is an inference-only path: use torch.no_grad()")
+            return self._forward_train(tokens, species_type_ids)
         if need_head_weights:
             return self._forward_with_attentions(tokens, species_type_ids, repr_layers)
         B, T = tokens.shape
@@ -190,6 +194,16 @@ class ProteinBertModel(nn.Module):
         if self.check_indices and int(status.item()) != 0:
             raise IndexError("token or species id out of range")
         return {"logits": logits, "struct_label_output": struct, "representations": reps}
+
+    def _forward_train(self, tokens, species_type_ids):
+        """Differentiable forward (the training_step call of pretraining.py:103): logits and
+        structure logits carry the autograd graph; no representations are returned."""
+        from .train import EncoderTrainFunction, train_parameters
+        tok32 = tokens.to(torch.int32).contiguous()
+        sp32 = species_type_ids.to(device=tokens.device, dtype=torch.int32).contiguous()
+        assert sp32.numel() == tokens.shape[0]
+        logits, struct = EncoderTrainFunction.apply(self, tok32, sp32, *train_parameters(self))
+        return {"logits": logits, "struct_label_output": struct, "representations": {}}
 
     def _forward_with_attentions(self, tokens, species_type_ids, repr_layers):
         """Layer-by-layer path for need_head_weights=True (model.py:213-256): also returns

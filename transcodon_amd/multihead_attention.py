@@ -18,7 +18,7 @@ from .rotary import RotaryEmbedding
 
 
 def _param_key(params):
-    return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in params)
+    return (_lib.weights_epoch[0],) + tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in params)
 
 
 class MultiheadAttention(nn.Module):

@@ -1,0 +1,287 @@
+"""Training step on the MI355X kernels: autograd bridge, objective, optimiser, schedule.
+
+Mirrors ``CodonModel`` of the reference's pretraining.py:38-160 without Lightning:
+``ProteinBertModel.forward`` under grad mode goes through :class:`EncoderTrainFunction`
+(tc_encoder_forward_train / tc_encoder_backward), :func:`mlm_loss` is the objective of
+``training_step`` (:109-130), :class:`AdamW` + :func:`warmup_cosine` are
+``configure_optimizers`` (:64-92).  torch only owns memory, the autograd tape and the
+process group.
+"""
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import EncoderGrads, LayerGrads, check
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+def train_parameters(model):
+    """The parameters the forward uses, in the order EncoderTrainFunction returns gradients."""
+    ps = [model.embed_tokens.weight, model.species_embedding.weight,
+          model.emb_layer_norm_after.weight, model.emb_layer_norm_after.bias,
+          model.lm_head.dense.weight, model.lm_head.dense.bias,
+          model.lm_head.layer_norm.weight, model.lm_head.layer_norm.bias, model.lm_head.bias,
+          model.structure_linear.dense.weight, model.structure_linear.dense.bias,
+          model.structure_linear.layer_norm.weight, model.structure_linear.layer_norm.bias,
+          model.structure_linear.out_proj.weight, model.structure_linear.out_proj.bias,
+          model.structure_linear.bias]
+    for l in model.layers:
+        a = l.self_attn
+        ps += [l.self_attn_layer_norm.weight, l.self_attn_layer_norm.bias,
+               a.q_proj.weight, a.k_proj.weight, a.v_proj.weight,
+               a.q_proj.bias, a.k_proj.bias, a.v_proj.bias,
+               a.out_proj.weight, a.out_proj.bias,
+               l.final_layer_norm.weight, l.final_layer_norm.bias,
+               l.fc1.weight, l.fc1.bias, l.fc2.weight, l.fc2.bias]
+    return ps
+
+
+class _GradPack:
+    """One zeroed f32 buffer holding every gradient in the kernels' packed layout, the C
+    struct that points into it, and the per-parameter views in train_parameters order."""
+
+    def __init__(self, model, device):
+        E, F = model.args.embed_dim, model.args.ffn_embed_dim
+        V, S, L = model.alphabet_size, model.args.species_vocab_size, len(model.layers)
+        head = [("tok_table", V * E), ("species_table", S * E), ("lnf_g", E), ("lnf_b", E),
+                ("w_heads", 2 * E * E), ("b_heads", 2 * E), ("lm_ln_g", E), ("lm_ln_b", E), ("lm_bias", V),
+                ("st_ln_g", E), ("st_ln_b", E), ("st_w", 3 * E), ("st_bias", 3)]
+        layer = [("ln1_g", E), ("ln1_b", E), ("w_qkv", 3 * E * E), ("b_qkv", 3 * E), ("w_o", E * E), ("b_o", E),
+                 ("ln2_g", E), ("ln2_b", E), ("w_fc1", F * E), ("b_fc1", F), ("w_fc2", E * F), ("b_fc2", E)]
+        off, hoff, loff = 0, {}, []
+        for n, sz in head:
+            hoff[n] = (off, sz)
+            off += _align(sz)
+        for _ in range(L):
+            d = {}
+            for n, sz in layer:
+                d[n] = (off, sz)
+                off += _align(sz)
+            loff.append(d)
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        base = self.flat.data_ptr()
+        self.layers = (LayerGrads * L)()
+        for i, d in enumerate(loff):
+            for n, (o, _) in d.items():
+                setattr(self.layers[i], n, base + 4 * o)
+        g = EncoderGrads()
+        for n, (o, _) in hoff.items():
+            setattr(g, n, base + 4 * o)
+        g.layers = C.cast(self.layers, C.POINTER(LayerGrads))
+        self.struct = g
+        v = lambda o_sz, *shape: self.flat[o_sz[0]:o_sz[0] + o_sz[1]].view(*shape)
+        w_heads, b_heads = v(hoff["w_heads"], 2 * E, E), v(hoff["b_heads"], 2 * E)
+        st_bias = v(hoff["st_bias"], 3)
+        views = [v(hoff["tok_table"], V, E), v(hoff["species_table"], S, E), v(hoff["lnf_g"], E), v(hoff["lnf_b"], E),
+                 w_heads[:E], b_heads[:E], v(hoff["lm_ln_g"], E), v(hoff["lm_ln_b"], E), v(hoff["lm_bias"], V),
+                 w_heads[E:], b_heads[E:], v(hoff["st_ln_g"], E), v(hoff["st_ln_b"], E), v(hoff["st_w"], 3, E),
+                 st_bias, st_bias]
+        for d in loff:
+            w_qkv, b_qkv = v(d["w_qkv"], 3 * E, E), v(d["b_qkv"], 3 * E)
+            views += [v(d["ln1_g"], E), v(d["ln1_b"], E), w_qkv[:E], w_qkv[E:2 * E], w_qkv[2 * E:],
+                      b_qkv[:E], b_qkv[E:2 * E], b_qkv[2 * E:], v(d["w_o"], E, E), v(d["b_o"], E),
+                      v(d["ln2_g"], E), v(d["ln2_b"], E), v(d["w_fc1"], F, E), v(d["b_fc1"], F),
+                      v(d["w_fc2"], E, F), v(d["b_fc2"], E)]
+        self.views = views
+
+
+class EncoderTrainFunction(torch.autograd.Function):
+    """(tokens, species, parameters) -> (logits [B,T,V], struct logits [B,T,3]) with the HIP
+    forward; backward fills every parameter gradient with one tc_encoder_backward call."""
+
+    @staticmethod
+    def forward(ctx, model, tok32, sp32, *params):
+        B, T = tok32.shape
+        dev = tok32.device
+        dt = model._dtype()
+        pk = model._packed(dt, T, dev)
+        lib = _lib.load()
+        need = lib.tc_train_workspace_bytes(C.byref(pk["desc"]), B, T)
+        if need == 0:
+            raise _lib.HipLibraryError("tc_train_workspace_bytes: unsupported configuration")
+        ws = model._get_workspace(need, dev, train=True)
+        logits = torch.empty(B, T, model.alphabet_size, dtype=torch.float32, device=dev)
+        struct = torch.empty(B, T, 3, dtype=torch.float32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(lib.tc_encoder_forward_train(C.byref(pk["desc"]), tok32.data_ptr(), sp32.data_ptr(), B, T,
+                                           logits.data_ptr(), struct.data_ptr(), status.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), _stream()), "tc_encoder_forward_train")
+        if model.check_indices and int(status.item()) != 0:
+            raise IndexError("token or species id out of range")
+        model._train_generation += 1
+        ctx.model, ctx.pk, ctx.ws, ctx.tok32, ctx.sp32 = model, pk, ws, tok32, sp32
+        ctx.generation = model._train_generation
+        ctx.set_materialize_grads(False)
+        return logits, struct
+
+    @staticmethod
+    def backward(ctx, dlogits, dstruct):
+        model = ctx.model
+        if ctx.generation != model._train_generation:
+            raise RuntimeError("the saved activations were overwritten by a later forward: run backward "
+                               "before the next forward of the same model")
+        if dlogits is None and dstruct is None:
+            return (None,) * (3 + len(train_parameters(model)))
+        B, T = ctx.tok32.shape
+        dev = ctx.tok32.device
+        if dlogits is None:
+            dlogits = torch.zeros(B, T, model.alphabet_size, dtype=torch.float32, device=dev)
+        dlogits = dlogits.float().contiguous()
+        dstruct = None if dstruct is None else dstruct.float().contiguous()
+        gp = _GradPack(model, dev)
+        check(_lib.load().tc_encoder_backward(
+            C.byref(ctx.pk["desc"]), C.byref(gp.struct), ctx.tok32.data_ptr(), ctx.sp32.data_ptr(), B, T,
+            dlogits.data_ptr(), None if dstruct is None else dstruct.data_ptr(), ctx.ws.data_ptr(),
+            ctx.ws.numel(), _stream()), "tc_encoder_backward")
+        params = train_parameters(model)
+        grads = [g.to(p.dtype) if p.requires_grad else None for p, g in zip(params, gp.views)]
+        return (None, None, None, *grads)
+
+
+class _MlmLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, struct_logits, struct_labels, struct_weight):
+        lib = _lib.load()
+        M, V = labels.numel(), logits.shape[-1]
+        dev = logits.device
+        lg = logits.reshape(M, V).float().contiguous()
+        lb = labels.reshape(M).to(torch.int32).contiguous()
+        use_struct = struct_logits is not None and struct_labels is not None
+        S = struct_logits.shape[-1] if use_struct else 0
+        sl = struct_logits.reshape(M, S).float().contiguous() if use_struct else None
+        sb = struct_labels.reshape(M).to(torch.int32).contiguous() if use_struct else None
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        stats = torch.empty(4, dtype=torch.float32, device=dev)
+        dl = torch.empty_like(lg)
+        ds = torch.empty_like(sl) if use_struct else None
+        p = lambda t: None if t is None else t.data_ptr()
+        check(lib.tc_mlm_loss(p(lg), p(lb), p(sl), p(sb), p(loss), p(dl), p(ds), p(stats), struct_weight, 1.0,
+                              M, V, S, _stream()), "tc_mlm_loss")
+        ctx.save_for_backward(dl, ds) if use_struct else ctx.save_for_backward(dl)
+        ctx.shapes = (logits.shape, struct_logits.shape if use_struct else None)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        dl = (saved[0] * g).view(ctx.shapes[0])
+        ds = (saved[1] * g).view(ctx.shapes[1]) if len(saved) > 1 else None
+        return dl, None, ds, None, None
+
+
+def mlm_loss(logits, labels, struct_logits=None, struct_labels=None, struct_weight=0.4):
+    """pretraining.py:109-130: mean cross-entropy over labelled positions (ignore -100) plus
+    ``struct_weight`` times the structure cross-entropy when any structure label is set."""
+    if not logits.is_cuda:
+        raise _lib.HipLibraryError("mlm_loss runs on the GPU only (no CPU fallback)")
+    if struct_labels is None or struct_logits is None or not bool((struct_labels != -100).any()):
+        struct_logits = struct_labels = None      # pretraining.py:122: the term exists only with labels
+    return _MlmLossFunction.apply(logits, labels, struct_logits, struct_labels, struct_weight)
+
+
+def warmup_cosine(step, warmup_steps, num_steps):
+    """LambdaLR factor of pretraining.py:76-82."""
+    if step < warmup_steps:
+        return (step + 1) / warmup_steps
+    progress = (step - warmup_steps) / num_steps
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
+
+
+class FlatParameters:
+    """Re-homes parameters and their gradients into two flat f32 buffers, so that the optimiser
+    is one kernel launch and the data-parallel gradient mean one all-reduce.  For a
+    ProteinBertModel only the parameters its forward uses are taken (the others never receive
+    a gradient, so torch.optim.AdamW in the reference never touches them either)."""
+
+    def __init__(self, module_or_params):
+        from .model import ProteinBertModel
+        if isinstance(module_or_params, ProteinBertModel):
+            cand = train_parameters(module_or_params)
+        elif isinstance(module_or_params, torch.nn.Module):
+            cand = list(module_or_params.parameters())
+        else:
+            cand = list(module_or_params)
+        seen, params = set(), []
+        for p in cand:
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+        if not params or any(p.dtype != torch.float32 for p in params):
+            raise ValueError("FlatParameters needs float32 parameters")
+        dev = params[0].device
+        self.params = params
+        self.offsets, off = {}, 0
+        for p in params:
+            self.offsets[id(p)] = off
+            off += _align(p.numel(), 4)
+        self.data = torch.empty(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p in params:
+                o, n = self.offsets[id(p)], p.numel()
+                self.data[o:o + n].copy_(p.detach().reshape(-1))
+                if _align(n, 4) != n:
+                    self.data[o + n:o + _align(n, 4)].zero_()
+                p.data = self.data[o:o + n].view(p.shape)
+                p.grad = self.grad[o:o + n].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p in self.params:      # re-attach in case something replaced .grad
+            o, n = self.offsets[id(p)], p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + n].view(p.shape)
+
+    def ranges(self, exclude=()):
+        """Maximal contiguous [begin, end) element ranges that avoid the excluded parameters."""
+        skip = {id(p) for p in exclude}
+        out, start = [], None
+        for p in self.params:
+            o = self.offsets[id(p)]
+            if id(p) in skip:
+                if start is not None and o > start:
+                    out.append((start, o))
+                start = None
+            elif start is None:
+                start = o
+        if start is not None:
+            out.append((start, self.data.numel()))
+        return out
+
+
+class AdamW:
+    """torch.optim.AdamW semantics on a FlatParameters store with tc_adamw_step
+    (pretraining.py:64-70: lr 2e-4, weight decay 0.1 on every parameter)."""
+
+    def __init__(self, flat, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1):
+        self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(flat.data)
+        self.exp_avg_sq = torch.zeros_like(flat.data)
+        self.step_count = 0
+
+    def step(self, lr_factor=1.0, grad_scale=1.0, exclude=()):
+        """``exclude``: parameters without a gradient this step (torch skips those entirely,
+        weight decay included), e.g. the structure head while no structure label is set."""
+        self.step_count += 1
+        f = self.flat
+        for b, e in f.ranges(exclude):
+            check(_lib.load().tc_adamw_step(f.data.data_ptr() + 4 * b, f.grad.data_ptr() + 4 * b,
+                                            self.exp_avg.data_ptr() + 4 * b, self.exp_avg_sq.data_ptr() + 4 * b,
+                                            e - b, self.lr * lr_factor, self.betas[0], self.betas[1], self.eps,
+                                            self.weight_decay, self.step_count, grad_scale, _stream()),
+                  "tc_adamw_step")
+        _lib.weights_epoch[0] += 1   # parameters changed behind torch's version counters: repack
+
+
+def structure_head_parameters(model):
+    return list(model.structure_linear.parameters())
