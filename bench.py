@@ -87,12 +87,112 @@ def cpu_baseline(sd_cpu, tok, species, codes_per_seq, threads):
             "sample": f"{n_seq} seqs x {t.shape[1]} tokens x {iters} iters, torch fp32 oracle forward + decode, {dt:.1f} s"}
 
 
+def mlm_batch(B, T, seed):
+    """Masked-LM batch as the reference's collate builds it (pipeline.py:167-195): 25 % of the
+    positions selected, of which 80 % become <mask>, 10 % a random base, 10 % stay."""
+    tok, species, *_ = synthetic_batch(B, T, seed)
+    rng = np.random.default_rng(seed + 77)
+    tok = np.where(tok == 9, rng.integers(5, 9, tok.shape), tok).astype(np.int32)   # natural codons
+    labels = np.full((B, T), -100, np.int32)
+    special = (tok < 5)
+    sel = (rng.random((B, T)) < 0.25) & ~special
+    labels[sel] = tok[sel]
+    r = rng.random((B, T))
+    tok[sel & (r < 0.8)] = 9
+    rnd = sel & (r >= 0.8) & (r < 0.9)
+    tok[rnd] = rng.integers(5, 9, int(rnd.sum()))
+    return tok, species, labels
+
+
+def bench_train(args, world, rank, dev, dist_on):
+    """One step = forward, masked-LM loss, backward, gradient all-reduce (N > 1) and AdamW over
+    one micro-batch per GPU (pretraining.py:94-134 with accumulate_grad_batches = 1)."""
+    import torch.distributed as dist
+    from transcodon_amd import train as TR
+    from transcodon_amd.parallel import allreduce_grads
+    B, T = args.train_batch, args.train_seq_len
+    model = ta.ProteinBertModel(ta.default_args(), ta.Alphabet.from_architecture("CodonModel"))
+    ta.init_weights(model, seed=1236)
+    model = model.to(dev).train().set_compute_dtype(torch.bfloat16)
+    model.check_indices = False
+    flat = TR.FlatParameters(model)
+    opt = TR.AdamW(flat, lr=2e-4, weight_decay=0.1)
+    struct_params = TR.structure_head_parameters(model)
+    tok_np, sp_np, lab_np = mlm_batch(B, T, seed=1236 + rank)
+    tok, sp, labels = (torch.from_numpy(a).to(dev) for a in (tok_np, sp_np, lab_np))
+    losses = []
+
+    def step(i):
+        flat.zero_grad()
+        out = model(tok, sp)
+        loss = TR.mlm_loss(out["logits"], labels)        # structure labels are all -100 as shipped
+        loss.backward()
+        allreduce_grads(flat.grad)
+        opt.step(lr_factor=TR.warmup_cosine(i, 100, 10000), exclude=struct_params)
+        return loss
+
+    lib = _lib.load()
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    lib.tc_prof_reset()
+    lib.tc_prof_enable(1)
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses.append(step(args.warmup + i))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist_on:
+        dist.barrier()
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    lib.tc_prof_enable(0)
+    n, ms, flops = _lib.prof_collect(_lib.PROF_GEMM)
+    an, ams, aflops = _lib.prof_collect(_lib.PROF_ATTN)
+    if rank == 0:
+        tokens_total = world * B * T * args.steps
+        gemm_tflops = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # forward + data gradients + weight gradients of every linear layer (3x), attention
+        # forward 2 and backward 7 matrix products of 2*T*64 flops per token, head and layer
+        step_flops = 3 * (12 * 14155776 + 2379264) + 12 * 3072 * T * 4.5
+        model_tflops = tokens_total / world * step_flops / elapsed / 1e12
+        result = {
+            "metric": "MLM training tokens/sec (fwd+bwd+AdamW)", "value": round(tokens_total / elapsed, 1),
+            "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"configs[3]: masked-LM optimiser step, {B} seqs x {T} tokens per GPU, 25 % "
+                                   "positions selected (80/10/10), AdamW lr 2e-4 wd 0.1, gradient mean over ranks",
+                       "seqs_per_gpu": B, "seq_len": T, "parallelism": f"data-parallel x{world}",
+                       "first_loss": round(float(losses[0]), 4), "last_loss": round(float(losses[-1]), 4)},
+            "roofline": {"bound": "mfma", "kernel": "gemm kernels (all GEMM launches of the step)",
+                         "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n,
+                         "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
+                         "whole_step_tflops": round(model_tflops, 2),
+                         "whole_step_frac": round(model_tflops / PEAK_BF16_TFLOPS, 4)},
+            "kernels": {"gemm_ms_per_step": round(ms / args.steps, 3), "attn_ms_per_step": round(ams / args.steps, 3),
+                        "attn_tflops": round(aflops / (ams * 1e-3) / 1e12, 2) if ams > 0 else None},
+        }
+        print(json.dumps(result))
+    if dist_on:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=("infer", "train"), default="infer",
+                    help="infer: forward + decode (headline metric); train: masked-LM optimiser step")
+    ap.add_argument("--train-batch", type=int, default=32)
+    ap.add_argument("--train-seq-len", type=int, default=1024)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,6 +204,9 @@ def main():
     if dist_on:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.mode == "train":
+        return bench_train(args, world, rank, dev, dist_on)
 
     B, T = B_PER_GPU, SEQ_LEN
     model = ta.ProteinBertModel(ta.default_args(), ta.Alphabet.from_architecture("CodonModel"))
