@@ -199,6 +199,24 @@ int tc_mean_pool(const float *rep, const int32_t *start, const int32_t *len, flo
 int tc_transpose_cast(int in_dtype, int out_dtype, const void *in, int ld_in, void *out_t, int ldt,
                       void *out_rowmajor, int ld_rm, float *colsum, int M, int N, void *stream);
 
+/*
+ * Weight-gradient product on row-major bf16 operands, no transposed copies:
+ *   out[s][i, j] = sum over the s-th part of the rows m of A[m, i] * B[m, j]     (f32, s < splits)
+ * A [M, lda] is the output gradient dY, B [M, ldb] the layer input X, so that summing the
+ * `splits` slabs (tc_reduce_slabs) gives dW = dY^T X of a Linear layer.  I and J must be
+ * multiples of 128; slab s starts at out + s*I*ldo.
+ */
+int tc_gemm_tn(const void *A, int lda, const void *B, int ldb, float *out, int ldo, int M, int I, int J,
+               int splits, void *stream);
+
+/*
+ * colsum[n] += sum_m x[m, n] (f32, ACCUMULATED; the bias gradient of a Linear layer) for x of
+ * type dtype; for f32 input an optional bf16 copy of x is written on the way (bf16_copy
+ * [M, ld_copy]).  N must be a multiple of 8.
+ */
+int tc_colsum(int dtype, const void *x, int ld, void *bf16_copy, int ld_copy, float *colsum, int M, int N,
+              void *stream);
+
 /* out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s*n + i]: combines split-K partial products. */
 int tc_reduce_slabs(const float *slabs, float *out, int S, long n, int accumulate, void *stream);
 

@@ -220,3 +220,29 @@ def test_attention_backward(dtype, B, T, H, lens):
         assert err < (2e-2 if dtype == torch.bfloat16 else 2e-5), (name, err)
     if pad is not None:
         assert float(got[:, E:][pad.reshape(-1)].abs().max()) == 0.0   # padded keys get no gradient
+
+
+@pytest.mark.parametrize("M,I,J,splits", [(64, 128, 128, 1), (1000, 256, 384, 3), (33000, 768, 128, 16), (77, 128, 256, 4)])
+def test_gemm_tn_matches_matmul(M, I, J, splits):
+    """dW = dY^T X straight from row-major operands (ragged last token tile, more splits than tiles)."""
+    a, b = _bf(_rand(M, I, seed=41)), _bf(_rand(M, J, seed=42))
+    slabs = ops.gemm_tn(a.to(DEV, torch.bfloat16), b.to(DEV, torch.bfloat16), splits)
+    got = ops.reduce_slabs(slabs).cpu()
+    ref = a.t().double() @ b.double()
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(got.numpy() / scale, ref.numpy() / scale, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_colsum(dtype):
+    M, N = 1234, 200
+    x = _rand(M, N, seed=43)
+    if dtype == torch.bfloat16:
+        x = _bf(x)
+    base = torch.ones(N, device=DEV)
+    if dtype == torch.float32:
+        out, copy = ops.colsum(x.to(DEV), want_bf16_copy=True, out=base)
+        assert torch.equal(copy.cpu(), x.to(torch.bfloat16))
+    else:
+        out = ops.colsum(x.to(DEV, dtype), out=base)
+    np.testing.assert_allclose(out.cpu().numpy(), 1.0 + x.double().sum(0).numpy(), rtol=1e-5, atol=1e-4)

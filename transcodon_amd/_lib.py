@@ -75,6 +75,8 @@ _SIGNATURES = {
                                 C.c_int, C.c_int, C.c_int, vp]),
     "tc_transpose_cast": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp,
                                     C.c_int, C.c_int, vp]),
+    "tc_gemm_tn": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "tc_colsum": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "tc_reduce_slabs": (C.c_int, [vp, vp, C.c_int, C.c_long, C.c_int, vp]),
     "tc_layernorm_bwd": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int,
                                    C.c_float, vp]),

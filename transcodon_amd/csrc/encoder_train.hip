@@ -133,12 +133,25 @@ int linear_wgrad(const tc_encoder_desc *d, TrainWs &w, int in_dt, const void *dy
     const int esz = dt == TC_BF16 ? 2 : 4;
     const int Mp = (M + 63) / 64 * 64;
     const int nk = Mp / (128 / esz);
-    TC_TRY(tc_transpose_cast(in_dt, dt, dy, n_out, w.tr_a, Mp, dy_rowmajor, n_out, dbias, M, n_out, stream));
-    TC_TRY(tc_transpose_cast(dt, dt, x, n_in, w.tr_b, Mp, nullptr, 0, nullptr, M, n_in, stream));
     const int splits = wgrad_splits(n_out, n_in, nk);
     TC_REQUIRE((size_t)splits * n_out * n_in <= w.slab_floats, "linear_wgrad: slab buffer too small");
-    TC_TRY(tc_gemm_train(dt, TC_EPI_PLAIN_F32, w.tr_a, Mp, w.tr_b, nullptr, nullptr, w.slabs, nullptr, n_in, n_out,
-                         n_in, Mp, splits, stream));
+    if (dt == TC_BF16) {
+        // row-major operands straight into the transposing-read GEMM
+        const void *dyb = dy;
+        if (in_dt == TC_F32) {
+            TC_REQUIRE(dy_rowmajor != nullptr, "linear_wgrad: f32 gradient needs a bf16 staging buffer");
+            TC_TRY(tc_colsum(TC_F32, dy, n_out, dy_rowmajor, n_out, dbias, M, n_out, stream));
+            dyb = dy_rowmajor;
+        } else {
+            TC_TRY(tc_colsum(TC_BF16, dy, n_out, nullptr, 0, dbias, M, n_out, stream));
+        }
+        TC_TRY(tc_gemm_tn(dyb, n_out, x, n_in, w.slabs, n_in, M, n_out, n_in, splits, stream));
+    } else {
+        TC_TRY(tc_transpose_cast(in_dt, dt, dy, n_out, w.tr_a, Mp, dy_rowmajor, n_out, dbias, M, n_out, stream));
+        TC_TRY(tc_transpose_cast(dt, dt, x, n_in, w.tr_b, Mp, nullptr, 0, nullptr, M, n_in, stream));
+        TC_TRY(tc_gemm_train(dt, TC_EPI_PLAIN_F32, w.tr_a, Mp, w.tr_b, nullptr, nullptr, w.slabs, nullptr, n_in,
+                             n_out, n_in, Mp, splits, stream));
+    }
     TC_TRY(tc_reduce_slabs(w.slabs, dW, splits, (long)n_out * n_in, 1, stream));
     return TC_OK;
 }

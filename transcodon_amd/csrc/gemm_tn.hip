@@ -1,0 +1,247 @@
+// Weight-gradient GEMM on row-major operands (gfx950, bf16):
+//   C[I,J] = sum_m A[m,I] * B[m,J]          A = dY [M, lda], B = X [M, ldb], C f32
+// The reduction runs over the slow (token) dimension of both operands, so neither has the
+// "k contiguous" layout the matrix cores want.  Tiles of 64 tokens x 128 columns are staged
+// row-major with direct global->LDS loads and the fragments are read with the transposing LDS
+// read (ds_read_b64_tr_b16), which hands every lane four consecutive-token values of its
+// column: no transposed copy of dY or X is ever written to memory.
+// Workgroup: 256 threads, 128x128 output tile, 2x2 waves of 64x64 (four 32x32x16 MFMA blocks).
+// grid.y splits the token range; split s writes its partial tile to out + s*slab (f32), to be
+// summed by tc_reduce_slabs (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int KT = 64;                         // tokens per stage
+constexpr int TILE_BYTES = KT * 256;           // 64 rows x 128 bf16
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+
+struct TnParams {
+    const char *A, *B;
+    float *out;
+    long lda_bytes, ldb_bytes, slab_elems;
+    int M, I, J, ldo, nk, splits, tiles_j;
+};
+
+// 16-byte chunk swizzle of a 256-byte row: the 8 rows one transposed read touches land on 8
+// different 32-byte bank spans.
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | (((row >> 2) & 1) << 1); }
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wi = wid >> 1, wj = wid & 1;
+    const int tile = tc_xcd_remap(blockIdx.x, gridDim.x);
+    const int i0 = (tile / p.tiles_j) * 128, j0 = (tile % p.tiles_j) * 128;
+    const int k_begin = (int)((long)p.nk * blockIdx.y / p.splits);
+    const int k_end = (int)((long)p.nk * (blockIdx.y + 1) / p.splits);
+
+    // staging: wave w loads rows [16w, 16w+16) of both tiles, 4 rows x 16 chunks per instruction
+    const int srow = lane >> 4, schunk = lane & 15;
+    long a_col[4], b_col[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wid * 16 + i * 4 + srow;
+        a_col[i] = (long)i0 * 2 + ((schunk ^ swz(r)) << 4);
+        b_col[i] = (long)j0 * 2 + ((schunk ^ swz(r)) << 4);
+    }
+    auto stage = [&](int buf, int kt) {
+        char *ab = smem + buf * STAGE_BYTES + wid * 16 * 256;
+        char *bb = ab + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = kt * KT + wid * 16 + i * 4 + srow;
+            m = m < p.M ? m : p.M - 1;
+            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(p.A + m * p.lda_bytes + a_col[i]),
+                                             TC_LDS_PTR(ab + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(p.B + m * p.ldb_bytes + b_col[i]),
+                                             TC_LDS_PTR(bb + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // transposed-read offsets: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a
+    // 4-row x 16-column block and receives the 4 rows of column (lane & 15)
+    const int tq = (lane & 15) >> 2, tp = lane & 3, thalf = (lane >> 4) & 1, h2 = lane >> 5;
+    int a_off[2][4][2], b_off[2][4][2];     // [block][k-step][lo/hi]
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int row = s * 16 + hi * 8 + 4 * h2 + tq;
+                const int ca = wi * 8 + blk * 4 + thalf * 2 + (tp >> 1);
+                const int cb = wj * 8 + blk * 4 + thalf * 2 + (tp >> 1);
+                a_off[blk][s][hi] = row * 256 + ((ca ^ swz(row)) << 4) + 8 * (tp & 1);
+                b_off[blk][s][hi] = TILE_BYTES + row * 256 + ((cb ^ swz(row)) << 4) + 8 * (tp & 1);
+            }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto frag = [&](const char *sb, int lo, int hi) {
+        const bf16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)(sb + lo));
+        const bf16x4 h = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)(sb + hi));
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] = l[j]; f[4 + j] = h[j]; }
+        return f;
+    };
+
+    if (k_begin < k_end) stage(0, k_begin);
+    for (int kt = k_begin; kt < k_end; ++kt) {
+        const int buf = (kt - k_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < k_end) stage(buf ^ 1, kt + 1);
+        char *sb = smem + buf * STAGE_BYTES;
+        const int valid = p.M - kt * KT;          // rows of this stage that exist
+        if (valid < KT) {                          // last, partial stage: zero the missing rows of A
+            for (int idx = threadIdx.x; idx < (KT - valid) * 16; idx += 256)
+                *reinterpret_cast<u32x4 *>(sb + (valid + (idx >> 4)) * 256 + (idx & 15) * 16) = u32x4{0u, 0u, 0u, 0u};
+            __syncthreads();
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                af[blk] = frag(sb, a_off[blk][s][0], a_off[blk][s][1]);
+                bf[blk] = frag(sb, b_off[blk][s][0], b_off[blk][s][1]);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    float *out = p.out + (long)blockIdx.y * p.slab_elems;
+    const int jl = lane & 31;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = j0 + wj * 64 + b * 32 + jl;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + wi * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                out[(long)i * p.ldo + j] = acc[a][b][r];
+            }
+        }
+}
+
+// column sums (and optional bf16 copy) of a row-major matrix: 8 columns per thread
+template <typename TI>
+__global__ __launch_bounds__(256) void colsum_kernel(const TI *__restrict__ x, long ld, uint16_t *__restrict__ copy,
+                                                     long ld_copy, float *__restrict__ colsum, int M, int N,
+                                                     int rows_per_block) {
+    __shared__ float red[32][65];
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;          // 8 column groups x 32 row lanes
+    const int n = blockIdx.x * 64 + cg * 8;
+    const int m_begin = blockIdx.y * rows_per_block;
+    const int m_end = min(M, m_begin + rows_per_block);
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    if (n < N) {
+        for (int m = m_begin + rl; m < m_end; m += 32) {
+            float v[8];
+            if constexpr (sizeof(TI) == 2) {
+                const u32x4 w = *reinterpret_cast<const u32x4 *>(x + m * ld + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[2 * j] = tc_bf16_lo(w[j]); v[2 * j + 1] = tc_bf16_hi(w[j]); }
+            } else {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(x + m * ld + n);
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(x + m * ld + n + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+                if (copy) {
+                    u32x4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = tc_pack_bf16(v[2 * j], v[2 * j + 1]);
+                    *reinterpret_cast<u32x4 *>(copy + m * ld_copy + n) = w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rl][cg * 8 + j] = s[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
+        const int col = blockIdx.x * 64 + threadIdx.x;
+        if (colsum && col < N) atomicAdd(colsum + col, t);
+    }
+}
+
+}  // namespace
+
+extern "C" int tc_gemm_tn(const void *A, int lda, const void *B, int ldb, float *out, int ldo, int M, int I, int J,
+                          int splits, void *stream) {
+    TC_REQUIRE(A && B && out, "tc_gemm_tn: null operand");
+    TC_REQUIRE(M > 0 && I > 0 && J > 0 && I % 128 == 0 && J % 128 == 0, "tc_gemm_tn: I=%d and J=%d must be multiples of 128",
+               I, J);
+    TC_REQUIRE(lda >= I && ldb >= J && ldo >= J && lda % 8 == 0 && ldb % 8 == 0, "tc_gemm_tn: bad leading dimensions");
+    TC_REQUIRE(tc_aligned16(A) && tc_aligned16(B) && tc_aligned16(out), "tc_gemm_tn: operands must be 16-byte aligned");
+    TC_REQUIRE(splits >= 1 && splits <= 256, "tc_gemm_tn: bad split count %d", splits);
+    TnParams p{};
+    p.A = static_cast<const char *>(A);
+    p.B = static_cast<const char *>(B);
+    p.out = out;
+    p.lda_bytes = (long)lda * 2;
+    p.ldb_bytes = (long)ldb * 2;
+    p.slab_elems = (long)I * ldo;
+    p.M = M; p.I = I; p.J = J; p.ldo = ldo;
+    p.nk = (M + KT - 1) / KT;
+    p.splits = splits;
+    p.tiles_j = J / 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) {
+            tc_set_error("tc_gemm_tn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return TC_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TcProfScope prof(TC_PROF_GEMM, s, 2.0 * (double)M * (double)I * (double)J);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((I / 128) * (J / 128), splits), dim3(256), LDS_BYTES, s, p);
+    TC_CHECK_LAUNCH("tc_gemm_tn");
+    return TC_OK;
+}
+
+extern "C" int tc_colsum(int dtype, const void *x, int ld, void *bf16_copy, int ld_copy, float *colsum, int M, int N,
+                         void *stream) {
+    TC_REQUIRE(dtype == TC_F32 || dtype == TC_BF16, "tc_colsum: bad dtype");
+    TC_REQUIRE(x && (colsum || bf16_copy) && M > 0 && N > 0 && N % 8 == 0 && ld >= N && ld % 8 == 0,
+               "tc_colsum: bad arguments (N and ld must be multiples of 8)");
+    TC_REQUIRE(!bf16_copy || (dtype == TC_F32 && ld_copy >= N && ld_copy % 8 == 0),
+               "tc_colsum: the bf16 copy is for f32 input");
+    TC_REQUIRE(tc_aligned16(x) && tc_aligned16(bf16_copy), "tc_colsum: operands must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rows_per_block = 512;
+    const dim3 grid((N + 63) / 64, (M + rows_per_block - 1) / rows_per_block), block(256);
+    if (dtype == TC_BF16)
+        hipLaunchKernelGGL(colsum_kernel<uint16_t>, grid, block, 0, s, static_cast<const uint16_t *>(x), (long)ld,
+                           static_cast<uint16_t *>(nullptr), 0L, colsum, M, N, rows_per_block);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, static_cast<const float *>(x), (long)ld,
+                           static_cast<uint16_t *>(bf16_copy), (long)ld_copy, colsum, M, N, rows_per_block);
+    TC_CHECK_LAUNCH("tc_colsum");
+    return TC_OK;
+}

@@ -278,3 +278,26 @@ def attention_bwd(qkv, out, d_out, lse, B, T, H, key_words=None):
     check(_lib.load().tc_attn_bwd(_dt(qkv), _p(qkv), qkv.stride(0), _p(key_words), _p(out), _p(d_out), _p(lse),
                                   _p(delta), _p(d_qkv), d_qkv.stride(0), B, T, H, 64, _stream()), "tc_attn_bwd")
     return d_qkv
+
+
+def gemm_tn(a, b, splits=1):
+    """slabs[s] = partial a^T b over the s-th part of the rows; a [M,I], b [M,J] bf16 (tc_gemm_tn)."""
+    _dev(a, b)
+    M, I = a.shape
+    J = b.shape[1]
+    assert b.shape[0] == M and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    out = torch.empty(splits, I, J, dtype=torch.float32, device=a.device)
+    check(_lib.load().tc_gemm_tn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), J, M, I, J, splits, _stream()),
+          "tc_gemm_tn")
+    return out
+
+
+def colsum(x, want_bf16_copy=False, out=None):
+    """Column sums f32 [N] of x [M,N] (added to ``out`` when given) and, for f32 x, a bf16 copy."""
+    _dev(x, out)
+    M, N = x.shape
+    if out is None:
+        out = torch.zeros(N, dtype=torch.float32, device=x.device)
+    copy = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if want_bf16_copy else None
+    check(_lib.load().tc_colsum(_dt(x), _p(x), x.stride(0), _p(copy), N, _p(out), M, N, _stream()), "tc_colsum")
+    return (out, copy) if want_bf16_copy else out
