@@ -183,6 +183,21 @@ def bench_train(args, world, rank, dev, dist_on):
         dist.destroy_process_group()
 
 
+def pmc_traffic(path, prefix="gemm"):
+    """HBM bytes per launch of a kernel family from a committed counter pass (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE collected separately on this same command): launch-weighted mean."""
+    try:
+        with open(os.path.join(ROOT, "profiles", path)) as fh:
+            ks = json.load(fh)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    sel = [v for k, v in ks.items() if k.startswith(prefix)]
+    n = sum(v["dispatches"] for v in sel)
+    if not n:
+        return None
+    return round(sum((v["read_bytes"] + v["write_bytes"]) * v["dispatches"] for v in sel) / n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,6 +276,11 @@ def main():
         n, ms, flops = prof["gemm"]
         gemm_tflops = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         model_tflops = tokens_total / world * FLOPS_PER_TOKEN(T) / elapsed / 1e12
+        # operand + result bytes of the GEMMs of one forward (bf16 activations / weights, f32 residual stream)
+        M, E, F = B * T, 768, 3072
+        per_layer = (M * E * 2 + 3 * E * E * 2 + M * 3 * E * 2) + (M * E * 2 + E * E * 2 + 2 * M * E * 4) + \
+                    (M * E * 2 + F * E * 2 + M * F * 2) + (M * F * 2 + E * F * 2 + 2 * M * E * 4)
+        gemm_bytes = (12 * per_layer + M * E * 2 + 2 * E * E * 2 + M * 2 * E * 2) * args.steps
         extra = {}
         for name, unit, scale in (("attn", "TFLOP/s", 1e12), ("layernorm", "GB/s", 1e9),
                                   ("embed", "GB/s", 1e9), ("head", "GB/s", 1e9), ("decode", "GB/s", 1e9)):
@@ -279,7 +299,10 @@ def main():
                        "weights": "random init N(0,0.02), 89.8M params", "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16> (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
+                         "traffic": pmc_traffic("r01_pmc_traffic_infer.json"),
+                         "traffic_unit": "HBM bytes per GEMM launch (PMC pass of this command, committed under profiles/)",
+                         "algorithmic_bytes_per_launch": round(gemm_bytes / max(n, 1)),
                          "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
                          "whole_forward_tflops": round(model_tflops, 2),
                          "whole_forward_frac": round(model_tflops / PEAK_BF16_TFLOPS, 4)},

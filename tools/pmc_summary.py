@@ -14,14 +14,19 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(gemm_kernel\w*|attn_bf16_kernel|attn_f32_kernel|layernorm_kernel|head_kernel|embed_kernel|decode_kernel|key_mask_kernel)", name)
+    """Kernel family of a (possibly mangled) kernel name; None for kernels that are not ours."""
+    m = re.search(r"(gemm128_kernel|gemm256_kernel|gemm_tn_kernel|attn_bwd_dq_bf16_kernel|attn_bwd_dkv_bf16_kernel|"
+                  r"attn_bf16_kernel|attn_f32_kernel|layernorm_bwd_kernel|layernorm_kernel|head_bwd_kernel|"
+                  r"head_kernel|embed_bwd_kernel|embed_kernel|decode_kernel|key_mask_kernel|colsum_kernel|"
+                  r"reduce_slabs_kernel|rope_bwd_kernel|adamw_kernel|delta_kernel|transpose_kernel)", name)
     if not m:
         return None
     base = m.group(1)
-    if base.startswith("gemm_kernel"):
-        e = re.search(r"Li(\d)E", name)
-        base = "gemm_kernel<epi=%s>" % (e.group(1) if e else "?")
-        if "IfLi" in name:
+    if base.startswith("gemm1") or base.startswith("gemm2"):
+        e = re.search(r"Li(\d)E", name) or re.search(r",\s*(\d)\s*>", name)
+        # the profiler's demangler garbles the <__bf16, 1> instantiation into "<bool _Accum, int, E>"
+        base += "<epi=%s>" % (e.group(1) if e else ("1" if "_Accum" in name else "?"))
+        if "IfLi" in name or "<float" in name:
             base += "f32"
     return base
 
@@ -53,6 +58,19 @@ def main(root):
             nw = max(len(calls[k].get("WRITE_SIZE", [])), 1)
             print("   -> HBM per dispatch: read %.1f MB (2 x FETCH_SIZE), write %.1f MB" % (
                 2 * a.get("FETCH_SIZE", 0) * 1024 / nf / 1e6, a.get("WRITE_SIZE", 0) * 1024 / nw / 1e6))
+
+
+    if len(sys.argv) > 2:      # machine-readable HBM traffic per dispatch for bench.py
+        import json
+        out = {}
+        for k, a in acc.items():
+            if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
+                nf, nw = len(calls[k]["FETCH_SIZE"]), len(calls[k]["WRITE_SIZE"])
+                out[k] = {"read_bytes": 2 * a["FETCH_SIZE"] * 1024 / nf, "write_bytes": a["WRITE_SIZE"] * 1024 / nw,
+                          "dispatches": nf}
+        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per dispatch; "
+                             "reads = 2 x FETCH_SIZE KiB (gfx950 correction)", "kernels": out},
+                  open(sys.argv[2], "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
