@@ -104,3 +104,50 @@ def test_argument_checks_without_a_gpu():
     assert rc == -1 and b"head_dim" in lib.tc_last_error()
     rc = lib.tc_gemm(7, 0, 16, 64, 16, 16, None, 16, 128, 4, 128, 64, 0.0, None, None, 0, 0, None)
     assert rc == -1
+
+
+def _tiny_model(seed=3):
+    cfg = O.TINY
+    args = ta.default_args(num_layers=cfg.num_layers, embed_dim=cfg.embed_dim, ffn_embed_dim=cfg.ffn_embed_dim,
+                           attention_heads=cfg.attention_heads, species_vocab_size=cfg.species_vocab_size)
+    m = ta.ProteinBertModel(args, ta.Alphabet.from_architecture("CodonModel"))
+    return ta.init_weights(m, seed=seed)
+
+
+@pytest.mark.parametrize("ext", [".safetensors", ".ckpt"])
+def test_checkpoint_round_trip_with_reference_prefix(tmp_path, ext):
+    """Files carry the 'model.' prefix of the reference's CodonModel wrapper (infer.py:248-250);
+    the tied lm_head.weight is restored when safetensors left the alias out."""
+    from transcodon_amd import checkpoint
+    a, b = _tiny_model(3), _tiny_model(4)
+    path = str(tmp_path / ("w" + ext))
+    checkpoint.save(a, path, step=7)
+    raw = checkpoint.read_state_dict(path)
+    assert all(k.startswith("model.") for k in raw)
+    assert ("model.lm_head.weight" in raw) == (ext == ".ckpt")
+    checkpoint.load_into(b, path)
+    for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(v, w), k
+    assert b.lm_head.weight is b.embed_tokens.weight
+
+
+def test_checkpoint_without_prefix_and_bad_file(tmp_path):
+    from transcodon_amd import checkpoint
+    a, b = _tiny_model(5), _tiny_model(6)
+    path = str(tmp_path / "plain.pt")
+    torch.save(a.state_dict(), path)
+    checkpoint.load_into(b, path)
+    assert torch.equal(a.layers[1].fc2.weight, b.layers[1].fc2.weight)
+    torch.save({"something": 3}, str(tmp_path / "bad.pt"))
+    with pytest.raises(ValueError):
+        checkpoint.read_state_dict(str(tmp_path / "bad.pt"))
+
+
+def test_cli_parser_mirrors_reference_flags():
+    from transcodon_amd import infer
+    a = infer.build_parser().parse_args(["--model_checkpoint", "m.safetensors", "--input_data", "i.csv",
+                                         "--output_file", "o.csv", "--with_utr", "--batch_size", "6"])
+    assert (a.model_checkpoint, a.input_data, a.output_file, a.with_utr, a.batch_size) == \
+        ("m.safetensors", "i.csv", "o.csv", True, 6)
+    assert (a.num_layers, a.embed_dim, a.ffn_embed_dim, a.attention_heads, a.species_vocab_size) == \
+        (12, 768, 3072, 12, 1438)

@@ -256,3 +256,38 @@ def test_embedding_extraction_varlen(full_sd, full_f32):
         np.testing.assert_allclose(got[i].numpy(), ref.numpy(), atol=2e-4)
     full = ta.extract_embeddings(full_f32, seqs[:2], orgs[:2], pooled=False)
     assert [t.shape for t in full] == [(90, 768), (231, 768)]
+
+
+def test_cli_csv_round_trip(tmp_path):
+    """python -m transcodon_amd.infer on a small CSV: same flags and columns as infer.py:229-302,
+    predictions equal to the batched API and to the row-by-row embed_sequence path."""
+    import pandas as pd
+    from transcodon_amd import checkpoint, infer
+    cfg = O.TINY
+    sd = seeded_state_dict(cfg, 5, perturb=True)
+    m = _model(cfg, sd, torch.float32)
+    ck = str(tmp_path / "tiny.safetensors")
+    checkpoint.save(m, ck)
+    names = list(ta.ORGANISM2ID)[:cfg.species_vocab_size]
+    rows = {"protein_seq": ["MKT", "MALWMRLLPLLALLALWGPDPAAA", "MSRL", "M" * 40 + "LSR", "MGG"],
+            "organism": [names[1], names[0], names[7], names[3], names[1]],
+            "utr": ["ACGU", "GGGACU", "A", "CUCUCUGG", "UUAC"]}
+    src = str(tmp_path / "in.csv")
+    pd.DataFrame(rows).to_csv(src, index=False)
+    common = ["--model_checkpoint", ck, "--input_data", src, "--num_layers", str(cfg.num_layers), "--embed_dim",
+              str(cfg.embed_dim), "--ffn_embed_dim", str(cfg.ffn_embed_dim), "--attention_heads",
+              str(cfg.attention_heads), "--species_vocab_size", str(cfg.species_vocab_size)]
+    for with_utr in (False, True):
+        out = str(tmp_path / f"out{int(with_utr)}.csv")          # bare directory-less names also work
+        infer.main(common + ["--output_file", out] + (["--with_utr"] if with_utr else []) +
+                   (["--batch_size", "2"] if with_utr else []))
+        got = pd.read_csv(out)
+        assert list(got.columns) == ["organism", "protein_seq", "prediction_dna"]
+        assert list(got["protein_seq"]) == rows["protein_seq"] and list(got["organism"]) == rows["organism"]
+        want = ta.optimize_codons(m, rows["protein_seq"], rows["organism"], rows["utr"] if with_utr else None)
+        assert list(got["prediction_dna"]) == [w.replace("U", "T") for w in want]
+        for i in (0, 3):                                           # the reference's own row-by-row call
+            aa = rows["protein_seq"][i] + "_"
+            _, _, rna = ta.embed_sequence(m, rows["utr"][i] if with_utr else "false", ta.AA_tokenize(aa),
+                                          rows["organism"][i], aa)
+            assert rna.replace("U", "T") == got["prediction_dna"][i]
