@@ -142,43 +142,51 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
             }
         }
 
-        // mask + online softmax (base 2)
+        // mask + online softmax in base 2.  The running maximum is kept in scaled (log2) units, so
+        // the scale folds into one fma per pair in front of the exponential; the padded-key select
+        // runs only for tiles that contain a padded key (wave-uniform branch).
         const uint64_t word = key_word(p, b, kt);
-        const uint64_t wsh = word >> (4 * h2);
-        float tmax = -INFINITY;
+        if (word != ~0ull) {
+            const uint64_t wsh = word >> (4 * h2);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const uint32_t wk = (uint32_t)(wsh >> (32 * kb));
+            for (int kb = 0; kb < 2; ++kb) {
+                const uint32_t wk = (uint32_t)(wsh >> (32 * kb));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = acc_s[kb][r] * kLog2e;
-                if (word != ~0ull) {
+                for (int r = 0; r < 16; ++r) {
                     const int bit = (r & 3) + 8 * (r >> 2);
-                    s = ((wk >> bit) & 1u) ? s : -INFINITY;
+                    acc_s[kb][r] = ((wk >> bit) & 1u) ? acc_s[kb][r] : -INFINITY;
                 }
-                acc_s[kb][r] = s;
-                tmax = fmaxf(tmax, s);
             }
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-        float lsum = 0.f;
+        float tmax = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(acc_s[kb][r] - m_use);
-                acc_s[kb][r] = e;
-                lsum += e;
+            for (int r = 0; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(acc_s[kb][r], acc_s[kb][r + 1]));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * kLog2e;
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        const f32x2 scale2 = {kLog2e, kLog2e}, neg_m2 = {-m_use, -m_use};
+        f32x2 lsum2 = {0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 t = f32x2{acc_s[kb][r], acc_s[kb][r + 1]} * scale2 + neg_m2;
+                const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                acc_s[kb][r] = e[0];
+                acc_s[kb][r + 1] = e[1];
+                lsum2 += e;
             }
-        l_run = l_run * alpha + lsum;
+        l_run = l_run * alpha + (lsum2[0] + lsum2[1]);
         m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {      // skip when no lane's maximum moved
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+                for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+        }
 
         // O^T[d][query] += V^T . P^T ; P fragment of k-step (kb, s) = registers 8s..8s+7
 #pragma unroll

@@ -191,20 +191,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const BwdParams p
             }
         }
 
+        // P = exp2(S log2e - lse log2e), dS = P (dP - delta): packed f32 arithmetic; padded keys get
+        // S = -inf first (only in tiles that contain one: wave-uniform branch)
         const uint64_t word = key_word(p, b, kt);
-        const uint64_t wsh = word >> (4 * h2);
+        if (word != ~0ull) {
+            const uint64_t wsh = word >> (4 * h2);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const uint32_t wk = (uint32_t)(wsh >> (32 * kb));
+            for (int kb = 0; kb < 2; ++kb) {
+                const uint32_t wk = (uint32_t)(wsh >> (32 * kb));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pr = __builtin_amdgcn_exp2f(acc_s[kb][r] * kLog2e - lse2);
-                if (word != ~0ull) {
+                for (int r = 0; r < 16; ++r) {
                     const int bit = (r & 3) + 8 * (r >> 2);
-                    pr = ((wk >> bit) & 1u) ? pr : 0.f;
+                    acc_s[kb][r] = ((wk >> bit) & 1u) ? acc_s[kb][r] : -INFINITY;
                 }
-                acc_s[kb][r] = pr * (acc_p[kb][r] - dlt);
             }
+        }
+        {
+            const f32x2 scale2 = {kLog2e, kLog2e}, neg_lse2 = {-lse2, -lse2}, neg_dlt2 = {-dlt, -dlt};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 t = f32x2{acc_s[kb][r], acc_s[kb][r + 1]} * scale2 + neg_lse2;
+                    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    const f32x2 ds = e * (f32x2{acc_p[kb][r], acc_p[kb][r + 1]} + neg_dlt2);
+                    acc_s[kb][r] = ds[0];
+                    acc_s[kb][r + 1] = ds[1];
+                }
         }
 
         // dQ^T[d][query] += K^T . dS^T
@@ -368,7 +381,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const BwdParams 
             }
         }
 
-        // P and dS; keep P in acc_s and dS in acc_p
+        // P and dS (packed f32 arithmetic); keep P in acc_s and dS in acc_p
+        const bool select = ragged || __builtin_amdgcn_ballot_w64(!k_ok) != 0ull;   // wave-uniform
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -376,15 +390,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const BwdParams 
                 const int qi = 32 * qb + 8 * g + 4 * h2;
                 const f32x4 l4 = *reinterpret_cast<const f32x4 *>(lse_s + qi);
                 const f32x4 d4 = *reinterpret_cast<const f32x4 *>(dlt_s + qi);
+                const f32x2 scale2 = {kLog2e, kLog2e};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; j += 2) {
                     const int r = 4 * g + j;
-                    float pr = __builtin_amdgcn_exp2f((acc_s[qb][r] - l4[j]) * kLog2e);
-                    bool ok = k_ok;
-                    if (ragged) ok = ok && (qt * 64 + qi + j < p.T);
-                    pr = ok ? pr : 0.f;
-                    acc_s[qb][r] = pr;
-                    acc_p[qb][r] = pr * (acc_p[qb][r] - d4[j]);
+                    const f32x2 t = (f32x2{acc_s[qb][r], acc_s[qb][r + 1]} - f32x2{l4[j], l4[j + 1]}) * scale2;
+                    f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    if (select) {
+                        e[0] = (k_ok && qt * 64 + qi + j < p.T) ? e[0] : 0.f;
+                        e[1] = (k_ok && qt * 64 + qi + j + 1 < p.T) ? e[1] : 0.f;
+                    }
+                    const f32x2 ds = e * (f32x2{acc_p[qb][r], acc_p[qb][r + 1]} - f32x2{d4[j], d4[j + 1]});
+                    acc_s[qb][r] = e[0];
+                    acc_s[qb][r + 1] = e[1];
+                    acc_p[qb][r] = ds[0];
+                    acc_p[qb][r + 1] = ds[1];
                 }
             }
 
