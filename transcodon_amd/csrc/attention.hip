@@ -37,7 +37,7 @@ constexpr int KV_TILE_BYTES = 64 * 128;            // 64 keys x 64 bf16
 constexpr int KV_STAGE_BYTES = 2 * KV_TILE_BYTES;  // K + V
 constexpr int OST_LD = 144;                        // bytes per staged output row (128 + pad)
 constexpr int OST_WAVE_BYTES = 32 * OST_LD;
-constexpr int ATTN_LDS_BYTES = 2 * KV_STAGE_BYTES + 4 * OST_WAVE_BYTES;
+constexpr int ATTN_LDS_BYTES = 2 * KV_STAGE_BYTES;   // the output staging reuses the K/V stages after the loop
 
 __device__ __forceinline__ int swz_k(int row) { return (row >> 1) & 7; }          // row reads
 __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }   // transposed reads
@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
     if (p.lse && h2 == 0 && q0 + ql < p.T)
         p.lse[((long)b * p.H + h) * p.T + q0 + ql] =
             l_tot > 0.f ? (m_run + __log2f(l_tot)) * 0.69314718055994531f : INFINITY;
-    char *ost = smem + 2 * KV_STAGE_BYTES + wid * OST_WAVE_BYTES;
+    __syncthreads();                       // every wave is done with the K/V stages
+    char *ost = smem + wid * OST_WAVE_BYTES;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll

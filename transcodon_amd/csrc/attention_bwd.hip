@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void delta_kernel(const T *__restrict__ o, con
 // bf16 dQ
 // ------------------------------------------------------------------------------------------
 constexpr int DQ_STAGE_BYTES = 3 * TILE_BYTES;                       // K rows, K for tr reads, V rows
-constexpr int DQ_LDS_BYTES = 2 * DQ_STAGE_BYTES + 4 * OST_WAVE_BYTES;
+constexpr int DQ_LDS_BYTES = 2 * DQ_STAGE_BYTES;      // the output staging reuses the stages after the loop
 
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const BwdParams p
             }
     }
 
-    char *ost = smem + 2 * DQ_STAGE_BYTES + wid * OST_WAVE_BYTES;
+    __syncthreads();
+    char *ost = smem + wid * OST_WAVE_BYTES;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
