@@ -272,12 +272,15 @@ int tc_attn_fwd_train(int dtype, const void *qkv, int ldq, const uint64_t *key_w
  *   d_qkv[:, 0:E] = dS K,  d_qkv[:, E:2E] = dS^T Q,  d_qkv[:, 2E:3E] = P^T d_out
  * with P = exp(S - lse) (0 at padded keys) and dS = P o (d_out V^T - delta),
  * delta[b,h,t] = sum_d d_out o out (f32 [B,H,T] scratch supplied by the caller, overwritten).
- * The gradients are with respect to the scaled, rotated q and rotated k: follow with
- * tc_rope_bwd.  d_qkv [B*T, ldg] has the element type `dtype`.  D must be 64.
+ * Without rope tables the gradients are with respect to the scaled, rotated q and rotated k.
+ * With rope_cos / rope_sin (f32 [T, D/2], as for TC_EPI_QKV_ROPE) the rotation and the q scale are
+ * undone on the way out (what tc_rope_bwd does), so d_qkv is the gradient of the q/k/v projection
+ * outputs.  d_qkv [B*T, ldg] has the element type `dtype`.  D must be 64.
  */
 int tc_attn_bwd(int dtype, const void *qkv, int ldq, const uint64_t *key_words, const void *out,
-                const void *d_out, const float *lse, float *delta, void *d_qkv, int ldg, int B, int T, int H,
-                int D, void *stream);
+                const void *d_out, const float *lse, float *delta, void *d_qkv, int ldg,
+                const float *rope_cos, const float *rope_sin, float q_scale, int B, int T, int H, int D,
+                void *stream);
 
 /* ---- whole-encoder convenience (one call per forward) ---------------------------- */
 

@@ -246,3 +246,22 @@ def test_colsum(dtype):
     else:
         out = ops.colsum(x.to(DEV, dtype), out=base)
     np.testing.assert_allclose(out.cpu().numpy(), 1.0 + x.double().sum(0).numpy(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_attention_backward_with_fused_rope(dtype):
+    """tc_attn_bwd with rope tables == tc_attn_bwd followed by tc_rope_bwd."""
+    B, T, H = 2, 200, 2
+    E, M = H * 64, B * T
+    qkv = _rand(M, 3 * E, seed=51, scale=0.5).to(DEV, dtype)
+    d_out = _rand(M, E, seed=52).to(DEV, dtype)
+    freqs = O.rope_freqs(64)
+    ang = torch.arange(T, dtype=torch.float32)[:, None] * freqs[None, :]
+    cos, sin = ang.cos().contiguous().to(DEV), ang.sin().contiguous().to(DEV)
+    pad = (torch.arange(T)[None, :] >= torch.tensor([T, 150])[:, None])
+    words = ops.key_mask_words(pad.to(DEV, torch.uint8).contiguous(), B, T)
+    out, lse = ops.attention_train(qkv, B, T, H, words)
+    plain = ops.attention_bwd(qkv, out, d_out, lse, B, T, H, words)
+    want = ops.rope_bwd(plain.clone(), cos, sin, T, E, 64, 0.125)
+    got = ops.attention_bwd(qkv, out, d_out, lse, B, T, H, words, cos, sin, 0.125)
+    np.testing.assert_array_equal(got.float().cpu().numpy(), want.float().cpu().numpy())

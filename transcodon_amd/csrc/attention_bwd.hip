@@ -32,6 +32,8 @@ struct BwdParams {
     const float *lse;     // [B,H,T]
     float *delta;         // [B,H,T]
     char *dqkv;           // [B*T, ldg]: dQ | dK | dV
+    const float *rope_cos, *rope_sin;   // optional [T, 32]: also undo the rotation (and q scale) of dQ, dK
+    float q_scale;
     long ldq_bytes, ldo_bytes, ldg_bytes;
     int B, T, H, E;
     int nw;               // validity words per sequence
@@ -45,6 +47,19 @@ __device__ __forceinline__ uint64_t key_word(const BwdParams &p, int b, int kt) 
     const int rem = p.T - kt * 64;
     const uint64_t in_range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
     return p.words ? (p.words[(long)b * p.nw + kt] & in_range) : in_range;
+}
+
+// Backward of the rotary rotation (and of the q scale) on 8 consecutive columns = 4 pairs of one
+// head, in the bf16 staging form: (d0, d1) <- (d0 c + d1 s, d1 c - d0 s) * scale.
+__device__ __forceinline__ u32x4 rope_bwd8(u32x4 w, const BwdParams &p, int pos, int chunk, float scale) {
+    const f32x4 cs = *reinterpret_cast<const f32x4 *>(p.rope_cos + (long)pos * 32 + chunk * 4);
+    const f32x4 sn = *reinterpret_cast<const f32x4 *>(p.rope_sin + (long)pos * 32 + chunk * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float d0 = tc_bf16_lo(w[j]), d1 = tc_bf16_hi(w[j]);
+        w[j] = tc_pack_bf16((d0 * cs[j] + d1 * sn[j]) * scale, (d1 * cs[j] - d0 * sn[j]) * scale);
+    }
+    return w;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -259,10 +274,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const BwdParams p
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int r = it * 8 + (lane >> 3), c = lane & 7;
-        const u32x4 w = *reinterpret_cast<const u32x4 *>(ost + r * OST_LD + c * 16);
+        u32x4 w = *reinterpret_cast<const u32x4 *>(ost + r * OST_LD + c * 16);
         const int q = q0 + r;
-        if (q < p.T)
+        if (q < p.T) {
+            if (p.rope_cos) w = rope_bwd8(w, p, q, c, p.q_scale);
             *reinterpret_cast<u32x4 *>(p.dqkv + (row_base + q) * p.ldg_bytes + (long)h * 128 + c * 16) = w;
+        }
     }
 }
 
@@ -462,9 +479,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const BwdParams 
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int r = it * 8 + (lane >> 3), c = lane & 7;
-            const u32x4 w = *reinterpret_cast<const u32x4 *>(ost + r * OST_LD + c * 16);
+            u32x4 w = *reinterpret_cast<const u32x4 *>(ost + r * OST_LD + c * 16);
             const int k = k0 + r;
-            if (k < p.T) *reinterpret_cast<u32x4 *>(p.dqkv + (row_base + k) * p.ldg_bytes + col + c * 16) = w;
+            if (k < p.T) {
+                if (which == 0 && p.rope_cos) w = rope_bwd8(w, p, k, c, 1.0f);
+                *reinterpret_cast<u32x4 *>(p.dqkv + (row_base + k) * p.ldg_bytes + col + c * 16) = w;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -624,8 +644,11 @@ int set_lds_attr(const void *fn, int bytes, const char *what) {
 }  // namespace
 
 extern "C" int tc_attn_bwd(int dtype, const void *qkv, int ldq, const uint64_t *key_words, const void *out,
-                           const void *d_out, const float *lse, float *delta, void *d_qkv, int ldg, int B, int T,
-                           int H, int D, void *stream) {
+                           const void *d_out, const float *lse, float *delta, void *d_qkv, int ldg,
+                           const float *rope_cos, const float *rope_sin, float q_scale, int B, int T, int H, int D,
+                           void *stream) {
+    TC_REQUIRE((rope_cos != nullptr) == (rope_sin != nullptr), "tc_attn_bwd: give both rope tables or neither");
+    TC_REQUIRE(tc_aligned16(rope_cos) && tc_aligned16(rope_sin), "tc_attn_bwd: rope tables must be 16-byte aligned");
     TC_REQUIRE(dtype == TC_BF16 || dtype == TC_F32, "tc_attn_bwd: bad dtype %d", dtype);
     TC_REQUIRE(qkv && out && d_out && lse && delta && d_qkv, "tc_attn_bwd: null operand");
     TC_REQUIRE(D == 64, "tc_attn_bwd: head_dim %d unsupported (only 64)", D);
@@ -644,6 +667,9 @@ extern "C" int tc_attn_bwd(int dtype, const void *qkv, int ldq, const uint64_t *
     p.lse = lse;
     p.delta = delta;
     p.dqkv = static_cast<char *>(d_qkv);
+    p.rope_cos = rope_cos;
+    p.rope_sin = rope_sin;
+    p.q_scale = q_scale;
     p.ldq_bytes = (long)ldq * esz;
     p.ldo_bytes = (long)E * esz;
     p.ldg_bytes = (long)ldg * esz;
@@ -690,6 +716,8 @@ extern "C" int tc_attn_bwd(int dtype, const void *qkv, int ldq, const uint64_t *
         TC_CHECK_LAUNCH("tc_attn_bwd(dq)");
         hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, dim3((unsigned)grid), dim3(64), 0, s, p);
         TC_CHECK_LAUNCH("tc_attn_bwd(dkv)");
+        if (rope_cos)     // the exactness path undoes the rotation with the standalone kernel
+            return tc_rope_bwd(dtype, d_qkv, ldg, rope_cos, rope_sin, B * T, T, E, D, q_scale, stream);
     }
     return TC_OK;
 }

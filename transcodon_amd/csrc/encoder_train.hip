@@ -305,9 +305,8 @@ extern "C" int tc_encoder_backward(const tc_encoder_desc *d, const tc_encoder_gr
         void *d_ao = w.tr_b;      // free between weight-gradient products
         TC_TRY(tc_gemm(dt, TC_EPI_BIAS, w.dyb, E, w.wt, nullptr, nullptr, d_ao, E, M, E, E, 0.f, nullptr, nullptr, 0, 0,
                        stream));
-        TC_TRY(tc_attn_bwd(dt, sv.qkv, 3 * E, w.words, sv.ao, d_ao, sv.lse, w.delta, w.wide, 3 * E, B, T, d->H, 64,
-                           stream));
-        TC_TRY(tc_rope_bwd(dt, w.wide, 3 * E, lw.rope_cos, lw.rope_sin, M, T, E, 64, 0.125f, stream));
+        TC_TRY(tc_attn_bwd(dt, sv.qkv, 3 * E, w.words, sv.ao, d_ao, sv.lse, w.delta, w.wide, 3 * E, lw.rope_cos,
+                           lw.rope_sin, 0.125f, B, T, d->H, 64, stream));
         TC_TRY(linear_wgrad(d, w, dt, w.wide, nullptr, sv.h1, M, 3 * E, E, lg.w_qkv, lg.b_qkv, stream));
         TC_TRY(transpose_weight(d, w, lw.w_qkv, 3 * E, E, stream));
         TC_TRY(tc_gemm_train(dt, TC_EPI_PLAIN_F32, w.wide, 3 * E, w.wt, nullptr, nullptr, w.t0, nullptr, E, M, E, 3 * E,

@@ -98,7 +98,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX *__restrict
             const int col = c * 256 + lane * 4;
             if (col < E) {
                 const TX *px = x + (long)row * ldx + col;
-                xv[c] = f32x4{to_f32<TX>(px[0]), to_f32<TX>(px[1]), to_f32<TX>(px[2]), to_f32<TX>(px[3])};
+                if constexpr (sizeof(TX) == 4) {
+                    xv[c] = *reinterpret_cast<const f32x4 *>(px);
+                } else {
+                    const u32x2 w = *reinterpret_cast<const u32x2 *>(px);
+                    xv[c] = f32x4{tc_bf16_lo(w[0]), tc_bf16_hi(w[0]), tc_bf16_lo(w[1]), tc_bf16_hi(w[1])};
+                }
                 dyv[c] = *reinterpret_cast<const f32x4 *>(dy + (long)row * E + col);
             } else {
                 xv[c] = f32x4{0, 0, 0, 0};
@@ -272,6 +277,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T *__restrict__ g, 
 // ---- embedding backward -------------------------------------------------------------------------
 // One workgroup per sequence: sums dx over the sequence's non-pad rows per token id (in LDS, each
 // thread owns its columns) and over all non-pad rows for the species row.
+constexpr int kEmbedBwdRows = 128;   // positions of one sequence per workgroup
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t *__restrict__ tokens,
                                                         const int32_t *__restrict__ species,
                                                         const float *__restrict__ dx,
@@ -280,12 +286,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t *__restric
                                                         int n_species, int pad_idx) {
     extern __shared__ float s_tok[];                 // [vocab][E]
     const int b = blockIdx.x;
+    const int t_begin = blockIdx.y * kEmbedBwdRows, t_end = min(T, t_begin + kEmbedBwdRows);
     for (int i = threadIdx.x; i < vocab * E; i += 256) s_tok[i] = 0.f;
     __syncthreads();
     const int sp = species[b];
     for (int col = threadIdx.x; col < E; col += 256) {
         float ssum = 0.f;
-        for (int t = 0; t < T; ++t) {
+        for (int t = t_begin; t < t_end; ++t) {
             const int tok = tokens[(long)b * T + t];
             if (tok == pad_idx || tok < 0 || tok >= vocab) continue;
             const float v = dx[((long)b * T + t) * E + col];
@@ -418,6 +425,8 @@ extern "C" int tc_layernorm_bwd(int x_dtype, const void *x, int ldx, const float
     TC_REQUIRE(x && gamma && dy && dx && dgamma && dbeta, "tc_layernorm_bwd: null operand");
     TC_REQUIRE(M > 0 && E > 0 && E % 4 == 0 && E <= 1024 && ldx >= E, "tc_layernorm_bwd: bad shape M=%d E=%d", M, E);
     TC_REQUIRE(x_dtype == TC_F32 || x_dtype == TC_BF16, "tc_layernorm_bwd: bad dtype");
+    TC_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x % (x_dtype == TC_F32 ? 16 : 8)) == 0 && tc_aligned16(dy) && tc_aligned16(dx),
+               "tc_layernorm_bwd: x rows must be 4-element aligned, dy and dx 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int blocks = (M + 3) / 4;
     if (blocks > 2048) blocks = 2048;
@@ -484,7 +493,7 @@ extern "C" int tc_embed_bwd(const int32_t *tokens, const int32_t *species, const
     TC_REQUIRE(tokens && species && dx && d_tok_table && d_species_table, "tc_embed_bwd: null operand");
     TC_REQUIRE(B > 0 && T > 0 && E > 0 && vocab > 0 && (size_t)vocab * E * 4 <= 64 * 1024,
                "tc_embed_bwd: bad shape (vocab*E*4 must fit 64 KiB of LDS)");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B), dim3(256), (size_t)vocab * E * 4, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B, (T + kEmbedBwdRows - 1) / kEmbedBwdRows), dim3(256), (size_t)vocab * E * 4, static_cast<hipStream_t>(stream),
                        tokens, species, dx, d_tok_table, d_species_table, T, E, vocab, n_species, pad_idx);
     TC_CHECK_LAUNCH("tc_embed_bwd");
     return TC_OK;

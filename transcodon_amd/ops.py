@@ -265,9 +265,10 @@ def attention_train(qkv, B, T, H, key_words=None):
     return out, lse
 
 
-def attention_bwd(qkv, out, d_out, lse, B, T, H, key_words=None):
-    """Gradient of attention() with respect to its qkv input (tc_attn_bwd) -> d_qkv like qkv."""
-    _dev(qkv, out, d_out, lse, key_words)
+def attention_bwd(qkv, out, d_out, lse, B, T, H, key_words=None, rope_cos=None, rope_sin=None, q_scale=1.0):
+    """Gradient of attention() with respect to its qkv input (tc_attn_bwd) -> d_qkv like qkv; with
+    rope tables, with respect to the unrotated, unscaled q/k/v projections."""
+    _dev(qkv, out, d_out, lse, key_words, rope_cos, rope_sin)
     E = H * 64
     if out.shape != (B * T, E) or d_out.shape != (B * T, E) or not out.is_contiguous() or not d_out.is_contiguous():
         raise ValueError("attention_bwd: out and d_out must be contiguous [B*T, E]")
@@ -276,7 +277,8 @@ def attention_bwd(qkv, out, d_out, lse, B, T, H, key_words=None):
     d_qkv = torch.empty(B * T, 3 * E, dtype=qkv.dtype, device=qkv.device)
     delta = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
     check(_lib.load().tc_attn_bwd(_dt(qkv), _p(qkv), qkv.stride(0), _p(key_words), _p(out), _p(d_out), _p(lse),
-                                  _p(delta), _p(d_qkv), d_qkv.stride(0), B, T, H, 64, _stream()), "tc_attn_bwd")
+                                  _p(delta), _p(d_qkv), d_qkv.stride(0), _p(rope_cos), _p(rope_sin), q_scale,
+                                  B, T, H, 64, _stream()), "tc_attn_bwd")
     return d_qkv
 
 
