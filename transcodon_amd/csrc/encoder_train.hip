@@ -43,9 +43,18 @@ struct TrainWs {
     size_t total;
 };
 
-int wgrad_splits(int n_out, int n_in, int nk) {
-    const long tiles = (long)((n_out + 127) / 128) * (n_in / 128);
-    long s = 1024 / (tiles > 0 ? tiles : 1);
+// Token-dimension split of a weight-gradient product.  bf16 with 256-divisible shapes runs the
+// 256 x 256 kernel, one workgroup per CU: as many splits as fill the chip once.  Otherwise
+// 128 x 128 tiles, about four workgroups per CU.
+int wgrad_splits(int dt, int n_out, int n_in, int nk) {
+    long s;
+    if (dt == TC_BF16 && n_out % 256 == 0 && n_in % 256 == 0) {
+        const long tiles = (long)(n_out / 256) * (n_in / 256);
+        s = 256 / tiles;
+    } else {
+        const long tiles = (long)((n_out + 127) / 128) * (n_in / 128);
+        s = 1024 / (tiles > 0 ? tiles : 1);
+    }
     if (s < 1) s = 1;
     if (s > 64) s = 64;
     if (s > nk) s = nk;
@@ -95,7 +104,7 @@ TrainWs carve(const tc_encoder_desc *d, int B, int T, char *base) {
     size_t sf = 0;
     const size_t shapes[4][2] = {{E, F}, {F, E}, {3 * E, E}, {E, E}};
     for (auto &sh : shapes) {
-        const size_t v = (size_t)wgrad_splits((int)sh[0], (int)sh[1], nk) * sh[0] * sh[1];
+        const size_t v = (size_t)wgrad_splits(d->dtype, (int)sh[0], (int)sh[1], nk) * sh[0] * sh[1];
         if (v > sf) sf = v;
     }
     w.slab_floats = sf;
@@ -133,7 +142,7 @@ int linear_wgrad(const tc_encoder_desc *d, TrainWs &w, int in_dt, const void *dy
     const int esz = dt == TC_BF16 ? 2 : 4;
     const int Mp = (M + 63) / 64 * 64;
     const int nk = Mp / (128 / esz);
-    const int splits = wgrad_splits(n_out, n_in, nk);
+    const int splits = wgrad_splits(dt, n_out, n_in, nk);
     TC_REQUIRE((size_t)splits * n_out * n_in <= w.slab_floats, "linear_wgrad: slab buffer too small");
     if (dt == TC_BF16) {
         // row-major operands straight into the transposing-read GEMM

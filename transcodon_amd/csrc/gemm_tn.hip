@@ -139,6 +139,123 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// 256 x 256 output tile, 8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA blocks): half the L2->LDS
+// bytes per flop of the 128 x 128 kernel.  One workgroup per CU (128 KiB of LDS); the host
+// picks the token split so that tiles x splits fills the chip once.
+// ------------------------------------------------------------------------------------------
+namespace big {
+constexpr int TILE_BYTES = KT * 512;           // 64 rows x 256 bf16
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;     // 128 KiB
+}  // namespace big
+
+__global__ __launch_bounds__(512) void gemm_tn256_kernel(const TnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wi = wid >> 2, wj = wid & 3;
+    const int tile = blockIdx.x;
+    const int i0 = (tile / p.tiles_j) * 256, j0 = (tile % p.tiles_j) * 256;
+    const int k_begin = (int)((long)p.nk * blockIdx.y / p.splits);
+    const int k_end = (int)((long)p.nk * (blockIdx.y + 1) / p.splits);
+
+    // staging: wave w loads rows [8w, 8w+8) of both tiles, 2 rows x 32 chunks per instruction
+    const int srow = lane >> 5, schunk = lane & 31;
+    long a_col[4], b_col[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wid * 8 + i * 2 + srow;
+        a_col[i] = (long)i0 * 2 + ((schunk ^ swz(r)) << 4);
+        b_col[i] = (long)j0 * 2 + ((schunk ^ swz(r)) << 4);
+    }
+    auto stage = [&](int buf, int kt) {
+        char *ab = smem + buf * big::STAGE_BYTES + wid * 8 * 512;
+        char *bb = ab + big::TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = kt * KT + wid * 8 + i * 2 + srow;
+            m = m < p.M ? m : p.M - 1;
+            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(p.A + m * p.lda_bytes + a_col[i]),
+                                             TC_LDS_PTR(ab + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(p.B + m * p.ldb_bytes + b_col[i]),
+                                             TC_LDS_PTR(bb + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // transposed reads: the row swizzle depends only on (row & 7) = 4*h2 + tq, a lane constant
+    const int tq = (lane & 15) >> 2, tp = lane & 3, thalf = (lane >> 4) & 1, h2 = lane >> 5;
+    const int row_l = 4 * h2 + tq;                        // + 16 s + 8 hi
+    const int sw = swz(row_l);
+    int a_base[4], b_base[2];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+        a_base[blk] = row_l * 512 + (((wi * 16 + blk * 4 + thalf * 2 + (tp >> 1)) ^ sw) << 4) + 8 * (tp & 1);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+        b_base[blk] = big::TILE_BYTES + row_l * 512 + (((wj * 8 + blk * 4 + thalf * 2 + (tp >> 1)) ^ sw) << 4) + 8 * (tp & 1);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto frag = [&](const char *sb, int off) {
+        const bf16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)(sb + off));
+        const bf16x4 h = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4 *)(sb + off + 8 * 512));
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] = l[j]; f[4 + j] = h[j]; }
+        return f;
+    };
+
+    if (k_begin < k_end) stage(0, k_begin);
+    for (int kt = k_begin; kt < k_end; ++kt) {
+        const int buf = (kt - k_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < k_end) stage(buf ^ 1, kt + 1);
+        char *sb = smem + buf * big::STAGE_BYTES;
+        const int valid = p.M - kt * KT;
+        if (valid < KT) {                          // last, partial stage: zero the missing rows of A
+            for (int idx = threadIdx.x; idx < (KT - valid) * 32; idx += 512)
+                *reinterpret_cast<u32x4 *>(sb + (valid + (idx >> 5)) * 512 + (idx & 31) * 16) = u32x4{0u, 0u, 0u, 0u};
+            __syncthreads();
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 bf[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) bf[blk] = frag(sb, b_base[blk] + s * 16 * 512);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const bf16x8 af = frag(sb, a_base[a] + s * 16 * 512);
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+
+    float *out = p.out + (long)blockIdx.y * p.slab_elems;
+    const int jl = lane & 31;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = j0 + wj * 64 + b * 32 + jl;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + wi * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                out[(long)i * p.ldo + j] = acc[a][b][r];
+            }
+        }
+}
+
 // column sums (and optional bf16 copy) of a row-major matrix: 8 columns per thread
 template <typename TI>
 __global__ __launch_bounds__(256) void colsum_kernel(const TI *__restrict__ x, long ld, uint16_t *__restrict__ copy,
@@ -210,8 +327,11 @@ extern "C" int tc_gemm_tn(const void *A, int lda, const void *B, int ldb, float 
     p.tiles_j = J / 128;
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn256_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
         if (e != hipSuccess) {
             tc_set_error("tc_gemm_tn: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return TC_ELAUNCH;
@@ -220,7 +340,14 @@ extern "C" int tc_gemm_tn(const void *A, int lda, const void *B, int ldb, float 
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     TcProfScope prof(TC_PROF_GEMM, s, 2.0 * (double)M * (double)I * (double)J);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((I / 128) * (J / 128), splits), dim3(256), LDS_BYTES, s, p);
+    // the large tile when it divides the problem and the launch still covers most of the chip
+    const long big_wgs = (long)(I / 256) * (J / 256) * splits;
+    if (I % 256 == 0 && J % 256 == 0 && big_wgs >= 192) {
+        p.tiles_j = J / 256;
+        hipLaunchKernelGGL(gemm_tn256_kernel, dim3((I / 256) * (J / 256), splits), dim3(512), big::LDS_BYTES, s, p);
+    } else {
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3((I / 128) * (J / 128), splits), dim3(256), LDS_BYTES, s, p);
+    }
     TC_CHECK_LAUNCH("tc_gemm_tn");
     return TC_OK;
 }
