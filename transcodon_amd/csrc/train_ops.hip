@@ -428,8 +428,10 @@ extern "C" int tc_layernorm_bwd(int x_dtype, const void *x, int ldx, const float
     TC_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x % (x_dtype == TC_F32 ? 16 : 8)) == 0 && tc_aligned16(dy) && tc_aligned16(dx),
                "tc_layernorm_bwd: x rows must be 4-element aligned, dy and dx 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // every workgroup ends with 2E global atomics onto the same addresses: 512 workgroups (two per
+    // CU) measured 86 us at M = 32768, E = 768 against 123 us with 2048 and 112 us with 256
     int blocks = (M + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     const int nch = (E + 255) / 256;
 #define TC_LNB(TX, N)                                                                                     \
     hipLaunchKernelGGL((layernorm_bwd_kernel<TX, N>), dim3(blocks), dim3(256), 0, s, static_cast<const TX *>(x), \
