@@ -176,3 +176,35 @@ def test_training_loop_reduces_loss_and_tracks_oracle():
         opt.step(exclude=TR.structure_head_parameters(m))
         losses.append(float(loss))
     np.testing.assert_allclose(losses, ref_losses, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_flat_store_gradients_equal_autograd_path(dtype):
+    """With a FlatParameters store the backward accumulates straight into the flat gradient
+    buffer; the result must equal the per-parameter gradients of the plain autograd path, and
+    a second micro-batch must add up (gradient accumulation)."""
+    cfg = O.TINY
+    sd = seeded_state_dict(cfg, 31, perturb=True)
+    tok, sp, labels, st = _batch(cfg, 3, 40, 9, pad_tail=(0, 3, 11), struct=True)
+    a, b = _model(cfg, sd, dtype), _model(cfg, sd, dtype)
+    flat = TR.FlatParameters(b)
+    assert b._flat_store is flat
+    for m in (a, b):
+        out = m(tok.to(DEV), sp.to(DEV))
+        TR.mlm_loss(out["logits"], labels.to(DEV), out["struct_label_output"], st.to(DEV)).backward()
+    ga = {k: p.grad for k, p in a.named_parameters() if p.grad is not None}
+    gb = {k: p.grad for k, p in b.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0}
+    assert set(ga) <= set(gb) | {k for k in ga if float(ga[k].abs().max()) == 0.0}
+    for k, g in ga.items():
+        # same kernels, same inputs; only the order of atomic additions may differ
+        np.testing.assert_allclose(b.get_parameter(k).grad.cpu().numpy(), g.cpu().numpy(), rtol=1e-4,
+                                   atol=1e-6 * max(1.0, float(g.abs().max())), err_msg=k)
+    # weights reach the kernels through the store: same forward output as the plain model
+    with torch.no_grad():
+        la = a(tok.to(DEV), sp.to(DEV))["logits"]
+        lb = b(tok.to(DEV), sp.to(DEV))["logits"]
+    np.testing.assert_array_equal(la.cpu().numpy(), lb.cpu().numpy())
+    out = b(tok.to(DEV), sp.to(DEV))
+    TR.mlm_loss(out["logits"], labels.to(DEV), out["struct_label_output"], st.to(DEV)).backward()
+    for k in ("layers.1.fc1.weight", "structure_linear.bias", "structure_linear.out_proj.bias", "embed_tokens.weight"):
+        np.testing.assert_allclose(b.get_parameter(k).grad.cpu().numpy(), 2 * ga[k].cpu().numpy(), rtol=1e-4, atol=1e-6)

@@ -78,6 +78,7 @@ class ProteinBertModel(nn.Module):
         self._workspace = None
         self._train_workspace = None
         self._train_generation = 0
+        self._flat_store = None         # train.FlatParameters, when the parameters live in one
 
     @property
     def num_layers(self):
@@ -96,7 +97,53 @@ class ProteinBertModel(nn.Module):
                                       else torch.float32)
 
     # -- device-side weight pack and descriptor --------------------------------------------
+    def _packed_from_store(self, dtype, T, device):
+        """Descriptor whose weight pointers go straight into the flat parameter store (or its
+        one-kernel shadow in the compute dtype): no per-tensor concatenation or cast."""
+        store = self._flat_store
+        rope_len = max(512, 1 << (T - 1).bit_length())
+        key = ("store", dtype, str(device), rope_len, _lib.weights_epoch[0], store.data._version)
+        if self._pack.get("key") == key:
+            return self._pack
+        lay = store.layout
+        with torch.no_grad():
+            lowp = store.shadow(dtype)
+            esz = lowp.element_size()
+            f32 = lambda o_sz: store.data.data_ptr() + 4 * o_sz[0]
+            cd = lambda o_sz: lowp.data_ptr() + esz * o_sz[0]
+            keep = {"lowp": lowp,
+                    "st_bias": (self.structure_linear.out_proj.bias.detach()
+                                + self.structure_linear.bias.detach()).float().contiguous()}
+            layers = (LayerWeights * len(self.layers))()
+            per_layer = []
+            for i, l in enumerate(self.layers):
+                d = lay.loff[i]
+                cos, sin = l.self_attn.rope.tables(rope_len, device)
+                per_layer.append((cos, sin))
+                for name in ("ln1_g", "ln1_b", "b_qkv", "b_o", "ln2_g", "ln2_b", "b_fc1", "b_fc2"):
+                    setattr(layers[i], name, f32(d[name]))
+                for name in ("w_qkv", "w_o", "w_fc1", "w_fc2"):
+                    setattr(layers[i], name, cd(d[name]))
+                layers[i].rope_cos, layers[i].rope_sin = cos.data_ptr(), sin.data_ptr()
+            d = EncoderDesc()
+            d.dtype = _lib.TC_BF16 if dtype == torch.bfloat16 else _lib.TC_F32
+            d.num_layers, d.E, d.F = len(self.layers), self.args.embed_dim, self.args.ffn_embed_dim
+            d.H, d.vocab = self.args.attention_heads, self.alphabet_size
+            d.n_species, d.n_struct, d.pad_idx = self.args.species_vocab_size, 3, self.padding_idx
+            d.rope_table_len, d.ln_eps = rope_len, self.emb_layer_norm_after.eps
+            h = lay.hoff
+            d.tok_table, d.species_table = f32(h["tok_table"]), f32(h["species_table"])
+            d.layers = C.cast(layers, C.POINTER(LayerWeights))
+            for name in ("lnf_g", "lnf_b", "b_heads", "lm_ln_g", "lm_ln_b", "lm_bias", "st_ln_g", "st_ln_b", "st_w"):
+                setattr(d, name, f32(h[name]))
+            d.w_heads = cd(h["w_heads"])
+            d.st_bias = keep["st_bias"].data_ptr()
+        self._pack = {"key": key, "desc": d, "layers": layers, "keep": keep, "per_layer": per_layer}
+        return self._pack
+
     def _packed(self, dtype, T, device):
+        if self._flat_store is not None and self._flat_store.data.device == device:
+            return self._packed_from_store(dtype, T, device)
         own = [self.embed_tokens.weight, self.species_embedding.weight,
                self.emb_layer_norm_after.weight, self.emb_layer_norm_after.bias,
                self.lm_head.dense.weight, self.lm_head.dense.bias, self.lm_head.layer_norm.weight,

@@ -46,53 +46,78 @@ def train_parameters(model):
     return ps
 
 
-class _GradPack:
-    """One zeroed f32 buffer holding every gradient in the kernels' packed layout, the C
-    struct that points into it, and the per-parameter views in train_parameters order."""
+class PackedLayout:
+    """Offsets (in f32 elements) of every trained tensor in the kernels' packed order: q/k/v
+    weights stacked as [3E,E], the two head dense layers as [2E,E].  ``st_bias`` is the single
+    gradient slot shared by structure_linear.out_proj.bias and structure_linear.bias;
+    ``st_bias2`` gives the second of them a slot of its own in a parameter store."""
 
-    def __init__(self, model, device):
+    HEAD = ("tok_table", "species_table", "lnf_g", "lnf_b", "w_heads", "b_heads", "lm_ln_g", "lm_ln_b",
+            "lm_bias", "st_ln_g", "st_ln_b", "st_w", "st_bias", "st_bias2")
+
+    def __init__(self, model):
         E, F = model.args.embed_dim, model.args.ffn_embed_dim
         V, S, L = model.alphabet_size, model.args.species_vocab_size, len(model.layers)
-        head = [("tok_table", V * E), ("species_table", S * E), ("lnf_g", E), ("lnf_b", E),
-                ("w_heads", 2 * E * E), ("b_heads", 2 * E), ("lm_ln_g", E), ("lm_ln_b", E), ("lm_bias", V),
-                ("st_ln_g", E), ("st_ln_b", E), ("st_w", 3 * E), ("st_bias", 3)]
+        self.dims = (E, F, V, S, L)
+        head = dict(tok_table=V * E, species_table=S * E, lnf_g=E, lnf_b=E, w_heads=2 * E * E, b_heads=2 * E,
+                    lm_ln_g=E, lm_ln_b=E, lm_bias=V, st_ln_g=E, st_ln_b=E, st_w=3 * E, st_bias=3, st_bias2=3)
         layer = [("ln1_g", E), ("ln1_b", E), ("w_qkv", 3 * E * E), ("b_qkv", 3 * E), ("w_o", E * E), ("b_o", E),
                  ("ln2_g", E), ("ln2_b", E), ("w_fc1", F * E), ("b_fc1", F), ("w_fc2", E * F), ("b_fc2", E)]
-        off, hoff, loff = 0, {}, []
-        for n, sz in head:
-            hoff[n] = (off, sz)
-            off += _align(sz)
+        off, self.hoff, self.loff = 0, {}, []
+        for n in self.HEAD:
+            self.hoff[n] = (off, head[n])
+            off += _align(head[n])
         for _ in range(L):
             d = {}
             for n, sz in layer:
                 d[n] = (off, sz)
                 off += _align(sz)
-            loff.append(d)
-        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
-        base = self.flat.data_ptr()
-        self.layers = (LayerGrads * L)()
-        for i, d in enumerate(loff):
+            self.loff.append(d)
+        self.total = off
+
+    def grads_struct(self, flat):
+        """tc_encoder_grads pointing into ``flat``; returns (struct, keep-alive layer array)."""
+        base = flat.data_ptr()
+        layers = (LayerGrads * len(self.loff))()
+        for i, d in enumerate(self.loff):
             for n, (o, _) in d.items():
-                setattr(self.layers[i], n, base + 4 * o)
+                setattr(layers[i], n, base + 4 * o)
         g = EncoderGrads()
-        for n, (o, _) in hoff.items():
-            setattr(g, n, base + 4 * o)
-        g.layers = C.cast(self.layers, C.POINTER(LayerGrads))
-        self.struct = g
-        v = lambda o_sz, *shape: self.flat[o_sz[0]:o_sz[0] + o_sz[1]].view(*shape)
+        for n, (o, _) in self.hoff.items():
+            if n != "st_bias2":
+                setattr(g, n, base + 4 * o)
+        g.layers = C.cast(layers, C.POINTER(LayerGrads))
+        return g, layers
+
+    def views(self, flat, own_second_bias):
+        """Per-parameter views of ``flat`` in train_parameters order.  own_second_bias: give
+        structure_linear.bias the st_bias2 slot (parameter stores) instead of aliasing st_bias."""
+        E, F, V, S, _ = self.dims
+        hoff = self.hoff
+        v = lambda o_sz, *shape: flat[o_sz[0]:o_sz[0] + o_sz[1]].view(*shape)
         w_heads, b_heads = v(hoff["w_heads"], 2 * E, E), v(hoff["b_heads"], 2 * E)
-        st_bias = v(hoff["st_bias"], 3)
         views = [v(hoff["tok_table"], V, E), v(hoff["species_table"], S, E), v(hoff["lnf_g"], E), v(hoff["lnf_b"], E),
                  w_heads[:E], b_heads[:E], v(hoff["lm_ln_g"], E), v(hoff["lm_ln_b"], E), v(hoff["lm_bias"], V),
                  w_heads[E:], b_heads[E:], v(hoff["st_ln_g"], E), v(hoff["st_ln_b"], E), v(hoff["st_w"], 3, E),
-                 st_bias, st_bias]
-        for d in loff:
+                 v(hoff["st_bias"], 3), v(hoff["st_bias2" if own_second_bias else "st_bias"], 3)]
+        for d in self.loff:
             w_qkv, b_qkv = v(d["w_qkv"], 3 * E, E), v(d["b_qkv"], 3 * E)
             views += [v(d["ln1_g"], E), v(d["ln1_b"], E), w_qkv[:E], w_qkv[E:2 * E], w_qkv[2 * E:],
                       b_qkv[:E], b_qkv[E:2 * E], b_qkv[2 * E:], v(d["w_o"], E, E), v(d["b_o"], E),
                       v(d["ln2_g"], E), v(d["ln2_b"], E), v(d["w_fc1"], F, E), v(d["b_fc1"], F),
                       v(d["w_fc2"], E, F), v(d["b_fc2"], E)]
-        self.views = views
+        return views
+
+
+class _GradPack:
+    """One zeroed f32 buffer holding every gradient in the kernels' packed layout, the C
+    struct that points into it, and the per-parameter views in train_parameters order."""
+
+    def __init__(self, model, device):
+        lay = PackedLayout(model)
+        self.flat = torch.zeros(lay.total, dtype=torch.float32, device=device)
+        self.struct, self.layers = lay.grads_struct(self.flat)
+        self.views = lay.views(self.flat, own_second_bias=False)
 
 
 class EncoderTrainFunction(torch.autograd.Function):
@@ -138,12 +163,22 @@ class EncoderTrainFunction(torch.autograd.Function):
             dlogits = torch.zeros(B, T, model.alphabet_size, dtype=torch.float32, device=dev)
         dlogits = dlogits.float().contiguous()
         dstruct = None if dstruct is None else dstruct.float().contiguous()
-        gp = _GradPack(model, dev)
+        store = getattr(model, "_flat_store", None)
+        struct = store.grads_struct if store is not None else None
+        gp = None
+        if struct is None:
+            gp = _GradPack(model, dev)
+            struct = gp.struct
         check(_lib.load().tc_encoder_backward(
-            C.byref(ctx.pk["desc"]), C.byref(gp.struct), ctx.tok32.data_ptr(), ctx.sp32.data_ptr(), B, T,
+            C.byref(ctx.pk["desc"]), C.byref(struct), ctx.tok32.data_ptr(), ctx.sp32.data_ptr(), B, T,
             dlogits.data_ptr(), None if dstruct is None else dstruct.data_ptr(), ctx.ws.data_ptr(),
             ctx.ws.numel(), _stream()), "tc_encoder_backward")
         params = train_parameters(model)
+        if gp is None:
+            # the kernels accumulated straight into the parameter store's gradient buffer (which
+            # the parameters' .grad attributes view): nothing for autograd to add
+            store.sync_shared_bias_grad()
+            return (None,) * (3 + len(params))
         grads = [g.to(p.dtype) if p.requires_grad else None for p, g in zip(params, gp.views)]
         return (None, None, None, *grads)
 
@@ -199,18 +234,46 @@ def warmup_cosine(step, warmup_steps, num_steps):
 
 class FlatParameters:
     """Re-homes parameters and their gradients into two flat f32 buffers, so that the optimiser
-    is one kernel launch and the data-parallel gradient mean one all-reduce.  For a
-    ProteinBertModel only the parameters its forward uses are taken (the others never receive
-    a gradient, so torch.optim.AdamW in the reference never touches them either)."""
+    is one kernel launch and the data-parallel gradient mean one all-reduce.
+
+    For a ProteinBertModel the buffers use the kernels' packed layout (PackedLayout) and hold
+    only the parameters its forward uses (the others never receive a gradient, so
+    torch.optim.AdamW in the reference never touches them either): the backward then
+    accumulates straight into ``grad`` and the GEMM weight pointers come straight out of
+    ``data`` (or of its one-kernel bf16 shadow) -- no per-tensor copies, adds or concatenations."""
 
     def __init__(self, module_or_params):
         from .model import ProteinBertModel
+        self.layout = None
+        self.grads_struct = None
         if isinstance(module_or_params, ProteinBertModel):
-            cand = train_parameters(module_or_params)
-        elif isinstance(module_or_params, torch.nn.Module):
-            cand = list(module_or_params.parameters())
-        else:
-            cand = list(module_or_params)
+            model = module_or_params
+            params = train_parameters(model)
+            if any(p.dtype != torch.float32 or not p.requires_grad for p in params):
+                raise ValueError("FlatParameters needs trainable float32 parameters")
+            dev = params[0].device
+            self.layout = PackedLayout(model)
+            self.data = torch.zeros(self.layout.total, dtype=torch.float32, device=dev)
+            self.grad = torch.zeros(self.layout.total, dtype=torch.float32, device=dev)
+            dviews = self.layout.views(self.data, own_second_bias=True)
+            gviews = self.layout.views(self.grad, own_second_bias=True)
+            self.params = params
+            self.spans = {}
+            with torch.no_grad():
+                for p, dv, gv in zip(params, dviews, gviews):
+                    dv.copy_(p.detach())
+                    p.data = dv
+                    p.grad = gv
+                    o = (dv.data_ptr() - self.data.data_ptr()) // 4
+                    self.spans[id(p)] = (o, o + p.numel())
+            self._gviews = gviews
+            self.grads_struct, self._grad_layers = self.layout.grads_struct(self.grad)
+            self._shadow = {}
+            model._flat_store = self
+            _lib.weights_epoch[0] += 1
+            return
+        cand = list(module_or_params.parameters()) if isinstance(module_or_params, torch.nn.Module) \
+            else list(module_or_params)
         seen, params = set(), []
         for p in cand:
             if p.requires_grad and id(p) not in seen:
@@ -220,42 +283,57 @@ class FlatParameters:
             raise ValueError("FlatParameters needs float32 parameters")
         dev = params[0].device
         self.params = params
-        self.offsets, off = {}, 0
+        self.spans, off = {}, 0
         for p in params:
-            self.offsets[id(p)] = off
+            self.spans[id(p)] = (off, off + p.numel())
             off += _align(p.numel(), 4)
-        self.data = torch.empty(off, dtype=torch.float32, device=dev)
+        self.data = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self._gviews = []
         with torch.no_grad():
             for p in params:
-                o, n = self.offsets[id(p)], p.numel()
-                self.data[o:o + n].copy_(p.detach().reshape(-1))
-                if _align(n, 4) != n:
-                    self.data[o + n:o + _align(n, 4)].zero_()
-                p.data = self.data[o:o + n].view(p.shape)
-                p.grad = self.grad[o:o + n].view(p.shape)
+                o, e = self.spans[id(p)]
+                self.data[o:e].copy_(p.detach().reshape(-1))
+                p.data = self.data[o:e].view(p.shape)
+                self._gviews.append(self.grad[o:e].view(p.shape))
+                p.grad = self._gviews[-1]
 
     def zero_grad(self):
         self.grad.zero_()
-        for p in self.params:      # re-attach in case something replaced .grad
-            o, n = self.offsets[id(p)], p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self.grad[o:o + n].view(p.shape)
+        for p, gv in zip(self.params, self._gviews):      # re-attach in case something replaced .grad
+            if p.grad is not gv:
+                p.grad = gv
+
+    def sync_shared_bias_grad(self):
+        """structure_linear.out_proj.bias and structure_linear.bias enter the forward as a sum:
+        the kernels accumulate one gradient, which the second parameter's slot mirrors."""
+        if self.layout is not None:
+            (o, n), (o2, _) = self.layout.hoff["st_bias"], self.layout.hoff["st_bias2"]
+            self.grad[o2:o2 + n].copy_(self.grad[o:o + n])
+
+    def shadow(self, dtype):
+        """``data`` in the compute dtype (itself for float32), refreshed when the weights changed."""
+        if dtype == torch.float32:
+            return self.data
+        key = (_lib.weights_epoch[0], self.data._version)
+        ent = self._shadow.get(dtype)
+        if ent is None or ent[0] != key:
+            buf = ent[1] if ent is not None else torch.empty_like(self.data, dtype=dtype)
+            buf.copy_(self.data)
+            self._shadow[dtype] = ent = (key, buf)
+        return ent[1]
 
     def ranges(self, exclude=()):
-        """Maximal contiguous [begin, end) element ranges that avoid the excluded parameters."""
-        skip = {id(p) for p in exclude}
-        out, start = [], None
-        for p in self.params:
-            o = self.offsets[id(p)]
-            if id(p) in skip:
-                if start is not None and o > start:
-                    out.append((start, o))
-                start = None
-            elif start is None:
-                start = o
-        if start is not None:
-            out.append((start, self.data.numel()))
+        """Maximal [begin, end) element ranges of the buffers that avoid the excluded parameters."""
+        cut = sorted(self.spans[id(p)] for p in exclude if id(p) in self.spans)
+        out, pos = [], 0
+        for b, e in cut:
+            b4, e4 = b // 4 * 4, _align(e, 4)          # keep every launch 16-byte aligned
+            if b4 > pos:
+                out.append((pos, b4))
+            pos = max(pos, e4)
+        if pos < self.data.numel():
+            out.append((pos, self.data.numel()))
         return out
 
 
