@@ -384,58 +384,64 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const BwdParams 
         const float *dlt_s = lse_s + 64;
         const bool ragged = qt * 64 + 64 > p.T;
 
-        // S[query][key], dP[query][key]
-        f32x16 acc_s[2], acc_p[2];
+        const bool select = ragged || __builtin_amdgcn_ballot_w64(!k_ok) != 0ull;   // wave-uniform
+        const f32x2 scale2 = {kLog2e, kLog2e};
+
+        // one block of 32 queries at a time keeps only 32 score registers live
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc_s[qb][r] = 0.f; acc_p[qb][r] = 0.f; }
+            // S[query][key] = Q K^T, dP[query][key] = dO V^T
+            bf16x8 qa[4], da[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 qa = *reinterpret_cast<const bf16x8 *>(sb + r_off[qb][ks]);
-                acc_s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], acc_s[qb], 0, 0, 0);
-                const bf16x8 da = *reinterpret_cast<const bf16x8 *>(sb + 2 * TILE_BYTES + r_off[qb][ks]);
-                acc_p[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], acc_p[qb], 0, 0, 0);
+                qa[ks] = *reinterpret_cast<const bf16x8 *>(sb + r_off[qb][ks]);
+                da[ks] = *reinterpret_cast<const bf16x8 *>(sb + 2 * TILE_BYTES + r_off[qb][ks]);
             }
-        }
-
-        // P and dS (packed f32 arithmetic); keep P in acc_s and dS in acc_p
-        const bool select = ragged || __builtin_amdgcn_ballot_w64(!k_ok) != 0ull;   // wave-uniform
+            f32x16 acc_s, acc_p;
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+            for (int r = 0; r < 16; ++r) { acc_s[r] = 0.f; acc_p[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], acc_s, 0, 0, 0);
+                acc_p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vf[ks], acc_p, 0, 0, 0);
+            }
+
+            // P = exp2((S - lse) log2e) into acc_s, dS = P (dP - delta) into acc_p
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int qi = 32 * qb + 8 * g + 4 * h2;
                 const f32x4 l4 = *reinterpret_cast<const f32x4 *>(lse_s + qi);
                 const f32x4 d4 = *reinterpret_cast<const f32x4 *>(dlt_s + qi);
-                const f32x2 scale2 = {kLog2e, kLog2e};
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
                     const int r = 4 * g + j;
-                    const f32x2 t = (f32x2{acc_s[qb][r], acc_s[qb][r + 1]} - f32x2{l4[j], l4[j + 1]}) * scale2;
-                    f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                    if (select) {
-                        e[0] = (k_ok && qt * 64 + qi + j < p.T) ? e[0] : 0.f;
-                        e[1] = (k_ok && qt * 64 + qi + j + 1 < p.T) ? e[1] : 0.f;
-                    }
-                    const f32x2 ds = e * (f32x2{acc_p[qb][r], acc_p[qb][r + 1]} - f32x2{d4[j], d4[j + 1]});
-                    acc_s[qb][r] = e[0];
-                    acc_s[qb][r + 1] = e[1];
-                    acc_p[qb][r] = ds[0];
-                    acc_p[qb][r + 1] = ds[1];
+                    const f32x2 t = (f32x2{acc_s[r], acc_s[r + 1]} - f32x2{l4[j], l4[j + 1]}) * scale2;
+                    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    const f32x2 ds = e * (f32x2{acc_p[r], acc_p[r + 1]} - f32x2{d4[j], d4[j + 1]});
+                    acc_s[r] = e[0];
+                    acc_s[r + 1] = e[1];
+                    acc_p[r] = ds[0];
+                    acc_p[r + 1] = ds[1];
+                }
+            }
+            if (select) {        // padded keys of this lane / queries past the end contribute nothing
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = qt * 64 + 32 * qb + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                    const bool ok = k_ok && q < p.T;
+                    acc_s[r] = ok ? acc_s[r] : 0.f;
+                    acc_p[r] = ok ? acc_p[r] : 0.f;
                 }
             }
 
-        // dV^T[d][key] += dO^T . P ;  dK^T[d][key] += Q^T . dS
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+            // dV^T[d][key] += dO^T . P ;  dK^T[d][key] += Q^T . dS
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 pf, df;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    pf[j] = (__bf16)acc_s[qb][8 * s + j];
-                    df[j] = (__bf16)acc_p[qb][8 * s + j];
+                    pf[j] = (__bf16)acc_s[8 * s + j];
+                    df[j] = (__bf16)acc_p[8 * s + j];
                 }
                 const int row0 = qb * 32 + 16 * s + 4 * h2 + tq;
 #pragma unroll
@@ -449,13 +455,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const BwdParams 
                         (__attribute__((address_space(3))) bf16x4 *)(sb + TILE_BYTES + o_lo));
                     const bf16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                         (__attribute__((address_space(3))) bf16x4 *)(sb + TILE_BYTES + o_hi));
-                    bf16x8 da, qa;
+                    bf16x8 dt, qt_;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { da[j] = dlo[j]; da[4 + j] = dhi[j]; qa[j] = qlo[j]; qa[4 + j] = qhi[j]; }
-                    acc_dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, pf, acc_dv[db], 0, 0, 0);
-                    acc_dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, df, acc_dk[db], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) { dt[j] = dlo[j]; dt[4 + j] = dhi[j]; qt_[j] = qlo[j]; qt_[4 + j] = qhi[j]; }
+                    acc_dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt, pf, acc_dv[db], 0, 0, 0);
+                    acc_dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_, df, acc_dk[db], 0, 0, 0);
                 }
             }
+        }
     }
 
     // ---- epilogue: dK then dV through the wave's staging rows (stage area is free now) ----
