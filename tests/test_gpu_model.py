@@ -291,3 +291,36 @@ def test_cli_csv_round_trip(tmp_path):
             _, _, rna = ta.embed_sequence(m, rows["utr"][i] if with_utr else "false", ta.AA_tokenize(aa),
                                           rows["organism"][i], aa)
             assert rna.replace("U", "T") == got["prediction_dna"][i]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_long_ragged_sequences_against_oracle(full_sd, full_f32, full_bf16, dtype):
+    """T = 1024 (the long-sequence configuration), one full row and one padded row."""
+    rng = np.random.default_rng(77)
+    B, T = 2, 1024
+    tok = np.full((B, T), O.PAD, np.int64)
+    for b, L in enumerate((T, 777)):
+        tok[b, :L] = [O.CLS] + list(rng.choice([5, 6, 7, 8, 9], L - 2)) + [O.EOS]
+    sp = rng.integers(0, 1438, B)
+    ref = O.forward(full_sd, O.FULL, torch.from_numpy(tok), torch.from_numpy(sp))
+    m = full_f32 if dtype == torch.float32 else full_bf16
+    with torch.no_grad():
+        out = m(torch.from_numpy(tok).to(DEV), torch.from_numpy(sp).to(DEV))
+    _check(out["logits"].cpu().numpy(), ref["logits"].numpy(), tok != O.PAD, dtype)
+
+
+def test_large_batch_matches_small_batch_bf16(full_bf16):
+    """At 64 x 512 tokens the persistent large-tile GEMM kernels run; a 4-sequence batch uses the
+    small-tile ones.  The same sequences must give the same logits either way (bf16 operands,
+    fp32 accumulation in both; only the summation order differs)."""
+    rng = np.random.default_rng(5)
+    T = 512
+    base = np.stack([[O.CLS] + list(rng.choice([5, 6, 7, 8, 9], T - 2)) + [O.EOS] for _ in range(4)])
+    sp4 = rng.integers(0, 1438, 4)
+    big, sp = np.tile(base, (16, 1)), np.tile(sp4, 16)
+    with torch.no_grad():
+        small = full_bf16(torch.from_numpy(base).to(DEV), torch.from_numpy(sp4).to(DEV))["logits"].cpu().numpy()
+        large = full_bf16(torch.from_numpy(big).to(DEV), torch.from_numpy(sp).to(DEV))["logits"].cpu().numpy()
+    for rep in (0, 7, 15):
+        d = np.abs(large[4 * rep:4 * rep + 4] - small)
+        assert float(d.max()) <= 0.03 and float(np.sqrt((d ** 2).mean())) <= 0.005, (rep, float(d.max()))
