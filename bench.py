@@ -87,23 +87,6 @@ def cpu_baseline(sd_cpu, tok, species, codes_per_seq, threads):
             "sample": f"{n_seq} seqs x {t.shape[1]} tokens x {iters} iters, torch fp32 oracle forward + decode, {dt:.1f} s"}
 
 
-def mlm_batch(B, T, seed):
-    """Masked-LM batch as the reference's collate builds it (pipeline.py:167-195): 25 % of the
-    positions selected, of which 80 % become <mask>, 10 % a random base, 10 % stay."""
-    tok, species, *_ = synthetic_batch(B, T, seed)
-    rng = np.random.default_rng(seed + 77)
-    tok = np.where(tok == 9, rng.integers(5, 9, tok.shape), tok).astype(np.int32)   # natural codons
-    labels = np.full((B, T), -100, np.int32)
-    special = (tok < 5)
-    sel = (rng.random((B, T)) < 0.25) & ~special
-    labels[sel] = tok[sel]
-    r = rng.random((B, T))
-    tok[sel & (r < 0.8)] = 9
-    rnd = sel & (r >= 0.8) & (r < 0.9)
-    tok[rnd] = rng.integers(5, 9, int(rnd.sum()))
-    return tok, species, labels
-
-
 def bench_train(args, world, rank, dev, dist_on):
     """One step = forward, masked-LM loss, backward, gradient all-reduce (N > 1) and AdamW over
     one micro-batch per GPU (pretraining.py:94-134 with accumulate_grad_batches = 1)."""
@@ -118,11 +101,16 @@ def bench_train(args, world, rank, dev, dist_on):
     flat = TR.FlatParameters(model)
     opt = TR.AdamW(flat, lr=2e-4, weight_decay=0.1)
     struct_params = TR.structure_head_parameters(model)
-    tok_np, sp_np, lab_np = mlm_batch(B, T, seed=1236 + rank)
-    tok, sp, labels = (torch.from_numpy(a).to(dev) for a in (tok_np, sp_np, lab_np))
+    tok_np, sp_np, _, _, _ = synthetic_batch(B, T, seed=1236 + rank)
+    rng = np.random.default_rng(1313 + rank)
+    tok_np = np.where(tok_np == 9, rng.integers(5, 9, tok_np.shape), tok_np).astype(np.int32)   # natural codons
+    tok_clean, sp = torch.from_numpy(tok_np).to(dev), torch.from_numpy(sp_np).to(dev)
+    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
     losses = []
 
     def step(i):
+        # fresh corruption of the clean batch every step, on the device (the collator's job)
+        tok, labels, _ = TR.mlm_mask(tok_clean, lens, seed=(1236 + rank) * 1000003 + i)
         flat.zero_grad()
         out = model(tok, sp)
         loss = TR.mlm_loss(out["logits"], labels)        # structure labels are all -100 as shipped
@@ -166,7 +154,7 @@ def bench_train(args, world, rank, dev, dist_on):
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"configs[3]: masked-LM optimiser step, {B} seqs x {T} tokens per GPU, 25 % "
-                                   "positions selected (80/10/10), AdamW lr 2e-4 wd 0.1, gradient mean over ranks",
+                                   "positions selected (80/10/10) on the device each step, AdamW lr 2e-4 wd 0.1, gradient mean over ranks",
                        "seqs_per_gpu": B, "seq_len": T, "parallelism": f"data-parallel x{world}",
                        "first_loss": round(float(losses[0]), 4), "last_loss": round(float(losses[-1]), 4)},
             "roofline": {"bound": "mfma", "kernel": "gemm kernels (all GEMM launches of the step)",

@@ -410,6 +410,20 @@ int tc_mlm_loss(const float *logits, const int32_t *labels, const float *struct_
                 float struct_weight, float upstream, int M, int V, int S, void *stream);
 
 /*
+ * Masked-LM corruption of a right-padded batch on the device, the arithmetic of DataCollator._mask_seq
+ * and DataPreprocessor (transcodon/pipeline.py:167-195, 343-361): per sequence of n = lens[b] tokens,
+ * num_changed = int(n * mask_proportion) distinct positions are drawn uniformly from 1..n-2; of these
+ * int(num_changed * mask_percent) become mask_idx, int(num_changed * leave_percent) keep their token and
+ * the rest get a uniformly drawn id from coding_ids.  labels = original token at the drawn positions,
+ * -100 elsewhere; struct_labels (optional, in place) is set to -100 outside the drawn positions.
+ * The reference draws from numpy's global generator; this uses a counter-based generator keyed by
+ * (seed, sequence, position), so the two agree in distribution, not draw by draw.
+ */
+int tc_mlm_mask(const int32_t *tokens, const int32_t *lens, int32_t *tokens_out, int32_t *labels,
+                int32_t *struct_labels, int B, int T, uint64_t seed, double mask_proportion, double mask_percent,
+                double leave_percent, int mask_idx, const int32_t *coding_ids, int n_coding, void *stream);
+
+/*
  * One AdamW update over n contiguous f32 values, torch.optim.AdamW semantics (pretraining.py:64-70:
  * decoupled weight decay on every parameter): p *= 1 - lr*wd; m, v moments of grad*grad_scale;
  * p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).  step counts from 1.

@@ -243,3 +243,45 @@ def test_full_config_gradients_match_oracle_autograd(dtype):
             assert err <= tol, (k, err)
             if dtype == torch.bfloat16:
                 assert cos >= 0.99, (k, cos)
+
+
+def test_mlm_mask_follows_the_collator_arithmetic():
+    """tc_mlm_mask against the counting rules of DataCollator._mask_seq (pipeline.py:167-195):
+    exact per-sequence counts, untouched <cls>/<eos>/padding, labels, replacement alphabet; the
+    draws themselves come from a different generator than numpy's (statistical agreement only)."""
+    rng = np.random.default_rng(0)
+    B, T = 64, 300
+    lens = rng.integers(3, T + 1, B)
+    lens[:3] = (3, 4, T)
+    tok = np.full((B, T), 1, np.int64)
+    for b, n in enumerate(lens):
+        tok[b, :n] = [0] + list(rng.integers(5, 9, n - 2)) + [2]
+    st = rng.integers(0, 3, (B, T))
+    out, labels, st_out = TR.mlm_mask(torch.from_numpy(tok).to(DEV), torch.from_numpy(lens).to(DEV), seed=123,
+                                      struct_labels=torch.from_numpy(st).to(DEV))
+    out, labels, st_out = out.cpu().numpy(), labels.cpu().numpy(), st_out.cpu().numpy()
+    n_masked = n_replaced = n_changed_total = 0
+    for b, n in enumerate(lens):
+        changed = int(n * 0.25)
+        changed = min(changed, n - 2)
+        want_mask, want_leave = int(changed * 0.8), int(changed * 0.1)
+        sel = labels[b] != -100
+        assert sel.sum() == changed and not sel[0] and not sel[n - 1:].any()
+        assert (labels[b][sel] == tok[b][sel]).all()
+        assert (out[b][~sel] == tok[b][~sel]).all()
+        assert (out[b][sel] == 9).sum() == want_mask
+        rest = out[b][sel][out[b][sel] != 9]
+        assert np.isin(rest, (5, 6, 7, 8)).all() and len(rest) == changed - want_mask
+        assert (st_out[b][~sel] == -100).all() and (st_out[b][sel] == st[b][sel]).all()
+        n_masked += want_mask
+        n_changed_total += changed
+    # positions are spread uniformly: first and second half of long rows get about the same share
+    long_rows = [b for b, n in enumerate(lens) if n > 200]
+    first = sum((labels[b, 1:lens[b] // 2] != -100).sum() for b in long_rows)
+    second = sum((labels[b, lens[b] // 2:lens[b] - 1] != -100).sum() for b in long_rows)
+    assert abs(first - second) < 0.15 * (first + second)
+    # another seed draws other positions; the same seed repeats exactly
+    out2, labels2, _ = TR.mlm_mask(torch.from_numpy(tok).to(DEV), torch.from_numpy(lens).to(DEV), seed=124)
+    out3, labels3, _ = TR.mlm_mask(torch.from_numpy(tok).to(DEV), torch.from_numpy(lens).to(DEV), seed=123)
+    assert not np.array_equal(labels2.cpu().numpy(), labels) and np.array_equal(labels3.cpu().numpy(), labels)
+    assert np.array_equal(out3.cpu().numpy(), out)

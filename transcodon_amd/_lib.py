@@ -99,6 +99,8 @@ _SIGNATURES = {
     "tc_encoder_backward": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderGrads), vp, vp, C.c_int, C.c_int,
                                       vp, vp, vp, C.c_size_t, vp]),
     "tc_mlm_loss": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, vp]),
+    "tc_mlm_mask": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_double,
+                              C.c_int, vp, C.c_int, vp]),
     "tc_adamw_step": (C.c_int, [vp, vp, vp, vp, C.c_long] + [C.c_float] * 5 + [C.c_int, C.c_float, vp]),
     "tc_prof_enable": (C.c_int, [C.c_int]),
     "tc_prof_reset": (C.c_int, []),

@@ -384,6 +384,59 @@ __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, const
     }
 }
 
+// ---- masked-LM corruption of a padded batch (pipeline.py:143-195) ----------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {     // finaliser of a counter-based generator
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+// One workgroup per sequence.  Every eligible position (all but the first and last token) draws a
+// 32-bit key; the num_changed smallest keys are the selected positions (a uniform sample without
+// replacement), ordered by key: the first num_mask become <mask>, the next num_leave stay, the
+// rest get a uniformly drawn coding token.
+__global__ __launch_bounds__(256) void mlm_mask_kernel(const int32_t *__restrict__ tokens,
+                                                       const int32_t *__restrict__ lens, int32_t *__restrict__ out,
+                                                       int32_t *__restrict__ labels, int32_t *__restrict__ struct_io,
+                                                       int T, uint64_t seed, double mask_prop, double mask_pct,
+                                                       double leave_pct, int mask_idx, int n_coding,
+                                                       const int32_t *__restrict__ coding) {
+    extern __shared__ uint32_t keys[];
+    const int b = blockIdx.x;
+    int n = lens[b];
+    n = n < 0 ? 0 : (n > T ? T : n);
+    int n_changed = (int)((double)n * mask_prop);
+    const int n_mask = (int)((double)n_changed * mask_pct);
+    const int n_leave = (int)((double)n_changed * leave_pct);
+    const int eligible = n - 2 > 0 ? n - 2 : 0;
+    if (n_changed > eligible) n_changed = eligible;
+    const uint32_t s0 = mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) + 0x9e3779b9u * (uint32_t)(b + 1)));
+    for (int t = threadIdx.x; t < eligible; t += 256) keys[t] = mix32(s0 + 0x85ebca6bu * (uint32_t)(t + 1));
+    __syncthreads();
+    const long row = (long)b * T;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        int tok = tokens[row + t];
+        int label = -100;
+        bool selected = false;
+        if (t >= 1 && t - 1 < eligible) {
+            const uint32_t k = keys[t - 1];
+            int rank = 0;
+            for (int u = 0; u < eligible; ++u) {
+                const uint32_t ku = keys[u];
+                rank += (ku < k) || (ku == k && u < t - 1);
+            }
+            if (rank < n_changed) {
+                selected = true;
+                label = tok;
+                if (rank < n_mask) tok = mask_idx;
+                else if (rank >= n_mask + n_leave) tok = coding[mix32(k ^ 0xc2b2ae35u) % (uint32_t)n_coding];
+            }
+        }
+        out[row + t] = tok;
+        labels[row + t] = label;
+        if (struct_io && !selected) struct_io[row + t] = -100;
+    }
+}
+
 }  // namespace
 
 extern "C" int tc_transpose_cast(int in_dtype, int out_dtype, const void *in, int ld_in, void *out_t, int ldt,
@@ -560,5 +613,21 @@ extern "C" int tc_adamw_step(float *param, const float *grad, float *exp_avg, fl
                        static_cast<hipStream_t>(stream), param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
                        weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
     TC_CHECK_LAUNCH("tc_adamw_step");
+    return TC_OK;
+}
+
+extern "C" int tc_mlm_mask(const int32_t *tokens, const int32_t *lens, int32_t *tokens_out, int32_t *labels,
+                           int32_t *struct_labels, int B, int T, uint64_t seed, double mask_proportion,
+                           double mask_percent, double leave_percent, int mask_idx, const int32_t *coding_ids,
+                           int n_coding, void *stream) {
+    TC_REQUIRE(tokens && lens && tokens_out && labels && coding_ids, "tc_mlm_mask: null operand");
+    TC_REQUIRE(B > 0 && T > 0 && T <= 16384 && n_coding > 0, "tc_mlm_mask: bad shape B=%d T=%d (T <= 16384)", B, T);
+    TC_REQUIRE(mask_proportion >= 0 && mask_proportion <= 1 && mask_percent >= 0 && leave_percent >= 0 &&
+                   mask_percent + leave_percent <= 1.0,
+               "tc_mlm_mask: bad proportions");
+    hipLaunchKernelGGL(mlm_mask_kernel, dim3(B), dim3(256), (size_t)T * 4, static_cast<hipStream_t>(stream), tokens, lens,
+                       tokens_out, labels, struct_labels, T, seed, mask_proportion, mask_percent, leave_percent, mask_idx,
+                       n_coding, coding_ids);
+    TC_CHECK_LAUNCH("tc_mlm_mask");
     return TC_OK;
 }

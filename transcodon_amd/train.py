@@ -224,6 +224,33 @@ def mlm_loss(logits, labels, struct_logits=None, struct_labels=None, struct_weig
     return _MlmLossFunction.apply(logits, labels, struct_logits, struct_labels, struct_weight)
 
 
+_CODING_CACHE = {}
+
+
+def mlm_mask(tokens, lens, seed, struct_labels=None, mask_proportion=0.25, mask_percent=0.8, leave_percent=0.1,
+             mask_idx=9, coding_ids=(5, 6, 7, 8)):
+    """Device-side DataCollator + DataPreprocessor (transcodon/pipeline.py:143-195, 343-361) for a
+    right-padded int batch: returns (corrupted tokens int32 [B,T], labels int32 [B,T] with -100 outside the
+    drawn positions, struct labels or None).  ``lens`` counts <cls> ... <eos> of each row; defaults are
+    pretraining.py:178-180 and the A/U/C/G replacement set of alphabet.py:55-57."""
+    if not tokens.is_cuda:
+        raise _lib.HipLibraryError("mlm_mask runs on the GPU only (no CPU fallback)")
+    B, T = tokens.shape
+    tok = tokens.to(torch.int32).contiguous()
+    ln = lens.to(device=tok.device, dtype=torch.int32).contiguous()
+    out, labels = torch.empty_like(tok), torch.empty_like(tok)
+    st = None if struct_labels is None else struct_labels.to(device=tok.device, dtype=torch.int32).contiguous().clone()
+    ckey = (tuple(coding_ids), str(tok.device))
+    coding = _CODING_CACHE.get(ckey)
+    if coding is None:          # a host-to-device copy synchronises: do it once per alphabet and device
+        coding = _CODING_CACHE[ckey] = torch.tensor(list(coding_ids), dtype=torch.int32, device=tok.device)
+    check(_lib.load().tc_mlm_mask(tok.data_ptr(), ln.data_ptr(), out.data_ptr(), labels.data_ptr(),
+                                  None if st is None else st.data_ptr(), B, T, int(seed) & (2 ** 64 - 1),
+                                  mask_proportion, mask_percent, leave_percent, mask_idx, coding.data_ptr(),
+                                  coding.numel(), _stream()), "tc_mlm_mask")
+    return out, labels, st
+
+
 def warmup_cosine(step, warmup_steps, num_steps):
     """LambdaLR factor of pretraining.py:76-82."""
     if step < warmup_steps:
