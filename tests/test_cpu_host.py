@@ -151,3 +151,27 @@ def test_cli_parser_mirrors_reference_flags():
         ("m.safetensors", "i.csv", "o.csv", True, 6)
     assert (a.num_layers, a.embed_dim, a.ffn_embed_dim, a.attention_heads, a.species_vocab_size) == \
         (12, 768, 3072, 12, 1438)
+
+
+def test_evaluation_metrics_against_reference_outputs(golden_dir):
+    """tests/golden/evaluation.json holds the outputs of the reference's own evaluation functions
+    (tools/gen_golden_eval.py) on random coding sequences and a random codon-usage table."""
+    from transcodon_amd import evaluation as EV
+    with open(os.path.join(golden_dir, "evaluation.json")) as fh:
+        g = json.load(fh)
+    usage = EV.CodonUsage({k: (v[0], v[1]) for k, v in g["codon_frequencies"].items()})
+    for c in g["cases"]:
+        assert EV.gc_content(c["dna"]) == pytest.approx(c["gc"], rel=1e-12)
+        assert EV.codon_similarity(c["dna"], c["other"]) == pytest.approx(c["similarity"], rel=1e-12)
+        assert EV.cfd(c["dna"], usage, 0.3) == pytest.approx(c["cfd"], rel=1e-12)
+        assert EV.cfd(c["dna"], usage, 0.5) == pytest.approx(c["cfd_05"], rel=1e-12)
+        for key, w in (("minmax", 18), ("minmax_w5", 5)):
+            got = EV.min_max_percentage(c["dna"], usage, w)
+            assert len(got) == len(c[key])
+            for a, b in zip(got, c[key]):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert a == pytest.approx(b, rel=1e-8, abs=1e-8)
+    assert EV.gc_content("ACGU".replace("U", "T")) == 50.0
+    with pytest.raises(KeyError):
+        EV.cfd("ATGNNN", usage)
