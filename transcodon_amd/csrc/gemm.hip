@@ -350,6 +350,165 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B (64 KiB)
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;     // 128 KiB
 }  // namespace k256
 
+// Accumulators of one 128 x 64 wave tile start at bias (+ residual): no bias registers are held
+// through the k-loop.  acc[ni][mi] = D[n][m] tiles of 16 x 16.
+template <typename T, int EPI>
+__device__ __forceinline__ void init_acc256(const GemmParams &p, f32x4 (&acc)[4][8], int mrow0, int ncol0) {
+    constexpr bool kPreloadResidual = EPI == TC_EPI_BIAS_RESIDUAL && sizeof(T) == 2;
+    {
+        f32x4 bias[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            bias[ni] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + ncol0 + ni * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            if constexpr (kPreloadResidual) {
+                const int m = mrow0 + mi * 16;
+                const float *rp = p.residual + (long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[ni][mi] = *reinterpret_cast<const f32x4 *>(rp + ni * 16) + bias[ni];
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = bias[ni];
+            }
+        }
+    }
+
+}
+
+// Epilogue of one wave tile.  Phase 1: arithmetic in place (its table loads are not queued
+// behind any store); phase 2: all stores.
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4][8], int tm, int tn, int mrow0,
+                                            int ncol0, int wm, int wn, int frow, int fgrp) {
+    using namespace k256;
+    constexpr bool kPreloadResidual = EPI == TC_EPI_BIAS_RESIDUAL && sizeof(T) == 2;
+    const int section = EPI == TC_EPI_QKV_ROPE ? (tn * BN) / p.E : 0;
+    if constexpr (EPI == TC_EPI_BIAS_GELU_SAVE) {
+        // pre-activation goes out first (kept for the backward pass), then GELU in place
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = mrow0 + mi * 16;
+            if (m < p.M) {
+                const long orow = (long)m * p.ldo + ncol0;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const f32x4 v = acc[ni][mi];
+                    u32x2 w;
+                    w[0] = tc_pack_bf16(v[0], v[1]);
+                    w[1] = tc_pack_bf16(v[2], v[3]);
+                    *reinterpret_cast<u32x2 *>(p.out2 + (orow + ni * 16) * 2) = w;
+                }
+            }
+        }
+    }
+    if constexpr (EPI == TC_EPI_DGELU) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = mrow0 + mi * 16;
+            const char *up = p.aux + ((long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0) * 2;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const u32x2 w = *reinterpret_cast<const u32x2 *>(up + ni * 32);
+                f32x4 v = acc[ni][mi];
+                v[0] *= gelu_grad<true>(tc_bf16_lo(w[0]));
+                v[1] *= gelu_grad<true>(tc_bf16_hi(w[0]));
+                v[2] *= gelu_grad<true>(tc_bf16_lo(w[1]));
+                v[3] *= gelu_grad<true>(tc_bf16_hi(w[1]));
+                acc[ni][mi] = v;
+            }
+        }
+    }
+    if constexpr (EPI == TC_EPI_BIAS_GELU || EPI == TC_EPI_BIAS_GELU_SAVE) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                f32x4 v = acc[ni][mi];
+                if constexpr (sizeof(T) == 2) {
+                    const f32x2 lo = gelu_fast2(f32x2{v[0], v[1]}), hi = gelu_fast2(f32x2{v[2], v[3]});
+                    v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = tc_gelu(v[e]);
+                }
+                acc[ni][mi] = v;
+            }
+    } else if constexpr (EPI == TC_EPI_QKV_ROPE) {
+        if (section < 2) {
+            const float qs = section == 0 ? p.q_scale : 1.0f;
+            const int half = p.head_dim >> 1;
+            // this lane's 4 columns of n-tile ni are rotary pairs pi(ni) + fgrp*2 + {0,1}
+            const int tile_pos0 = (tm * BM) % p.T;
+            const bool recur = sizeof(T) == 2 && tile_pos0 + BM <= p.T;
+            // No sequence boundary inside the tile (recur): rows 16 apart differ by a fixed
+            // angle, so only the first row's cos/sin are gathered (a gather touches 16 table
+            // rows per load instruction, which is what makes it expensive) and the other seven
+            // follow by angle addition with the table's row 16; 7 steps keep f32 accuracy.
+            // One n-tile at a time keeps the live rotary state at 8 registers.
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int pi = (((wn * 64 + ni * 16) % p.head_dim) >> 1) + fgrp * 2;
+                if (recur) {
+                    const long row = (long)(tile_pos0 + wm * 128 + frow) * half + pi;
+                    f32x2 c = *reinterpret_cast<const f32x2 *>(p.rope_cos + row);
+                    f32x2 sn = *reinterpret_cast<const f32x2 *>(p.rope_sin + row);
+                    const f32x2 c16 = *reinterpret_cast<const f32x2 *>(p.rope_cos + 16L * half + pi);
+                    const f32x2 s16 = *reinterpret_cast<const f32x2 *>(p.rope_sin + 16L * half + pi);
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        const f32x4 v = acc[ni][mi] * qs;
+                        acc[ni][mi] = f32x4{v[0] * c[0] - v[1] * sn[0], v[1] * c[0] + v[0] * sn[0],
+                                            v[2] * c[1] - v[3] * sn[1], v[3] * c[1] + v[2] * sn[1]};
+                        const f32x2 cn = c * c16 - sn * s16;
+                        sn = sn * c16 + c * s16;
+                        c = cn;
+                    }
+                } else {
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        const long row = (long)((mrow0 + mi * 16) % p.T) * half + pi;
+                        const f32x2 c = *reinterpret_cast<const f32x2 *>(p.rope_cos + row);
+                        const f32x2 sn = *reinterpret_cast<const f32x2 *>(p.rope_sin + row);
+                        const f32x4 v = acc[ni][mi] * qs;
+                        acc[ni][mi] = f32x4{v[0] * c[0] - v[1] * sn[0], v[1] * c[0] + v[0] * sn[0],
+                                            v[2] * c[1] - v[3] * sn[1], v[3] * c[1] + v[2] * sn[1]};
+                    }
+                }
+            }
+        }
+    } else if constexpr (EPI == TC_EPI_BIAS_RESIDUAL && !kPreloadResidual) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = mrow0 + mi * 16;
+            const float *rp = p.residual + (long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[ni][mi] = *reinterpret_cast<const f32x4 *>(rp + ni * 16) + acc[ni][mi];
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = mrow0 + mi * 16;
+        if (m < p.M) {
+            const long orow = (long)m * p.ldo + ncol0;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const f32x4 v = acc[ni][mi];
+                if constexpr (EPI == TC_EPI_BIAS_RESIDUAL || EPI == TC_EPI_PLAIN_F32 || sizeof(T) == 4) {
+                    *reinterpret_cast<f32x4 *>(p.out + (orow + ni * 16) * 4) = v;
+                } else {
+                    u32x2 w;
+                    w[0] = tc_pack_bf16(v[0], v[1]);
+                    w[1] = tc_pack_bf16(v[2], v[3]);
+                    *reinterpret_cast<u32x2 *>(p.out + (orow + ni * 16) * 2) = w;
+                }
+            }
+        }
+    }
+}
+
 // The MFMA operands are swapped here (A operand = W rows, B operand = activation rows), so an
 // accumulator tile is D[n][m]: the lane holds 4 CONSECUTIVE output columns n of one output row m.
 // The epilogue then needs no LDS: bias / GELU / rotary pairs / residual act on the lane's own 4
@@ -449,27 +608,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const int mrow0 = tm * BM + wm * 128 + frow;         // + mi*16
         const int ncol0 = tn * BN + wn * 64 + fgrp * 4;      // + ni*16
 
-        // accumulators start at bias (+ residual): no bias registers are held through the loop
         f32x4 acc[4][8];                                      // [ni][mi], D[n][m]
-        {
-            f32x4 bias[4];
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                bias[ni] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + ncol0 + ni * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                if constexpr (kPreloadResidual) {
-                    const int m = mrow0 + mi * 16;
-                    const float *rp = p.residual + (long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0;
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-                        acc[ni][mi] = *reinterpret_cast<const f32x4 *>(rp + ni * 16) + bias[ni];
-                } else {
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = bias[ni];
-                }
-            }
-        }
+        init_acc256<T, EPI>(p, acc, mrow0, ncol0);
 
         for (int kt = 0; kt < p.nk; ++kt, ++g) {
             TC_STAMP(s0);
@@ -479,7 +619,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             // critical path (the vector-memory counter retires in issue order).
             if (kt == 0 && t > 0 && prev_full) {
                 if constexpr (kPreloadResidual) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+                else if (p.bias) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      // no bias loads were issued
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -536,129 +677,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         // phase 1: arithmetic in place (its table loads are not queued behind any store);
         // phase 2: all stores.
         prev_full = (tm * BM + BM) <= p.M;
-        const int section = EPI == TC_EPI_QKV_ROPE ? (tn * BN) / p.E : 0;
-        if constexpr (EPI == TC_EPI_BIAS_GELU_SAVE) {
-            // pre-activation goes out first (kept for the backward pass), then GELU in place
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const int m = mrow0 + mi * 16;
-                if (m < p.M) {
-                    const long orow = (long)m * p.ldo + ncol0;
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
-                        const f32x4 v = acc[ni][mi];
-                        u32x2 w;
-                        w[0] = tc_pack_bf16(v[0], v[1]);
-                        w[1] = tc_pack_bf16(v[2], v[3]);
-                        *reinterpret_cast<u32x2 *>(p.out2 + (orow + ni * 16) * 2) = w;
-                    }
-                }
-            }
-        }
-        if constexpr (EPI == TC_EPI_DGELU) {
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const int m = mrow0 + mi * 16;
-                const char *up = p.aux + ((long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0) * 2;
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const u32x2 w = *reinterpret_cast<const u32x2 *>(up + ni * 32);
-                    f32x4 v = acc[ni][mi];
-                    v[0] *= gelu_grad<true>(tc_bf16_lo(w[0]));
-                    v[1] *= gelu_grad<true>(tc_bf16_hi(w[0]));
-                    v[2] *= gelu_grad<true>(tc_bf16_lo(w[1]));
-                    v[3] *= gelu_grad<true>(tc_bf16_hi(w[1]));
-                    acc[ni][mi] = v;
-                }
-            }
-        }
-        if constexpr (EPI == TC_EPI_BIAS_GELU || EPI == TC_EPI_BIAS_GELU_SAVE) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi) {
-                    f32x4 v = acc[ni][mi];
-                    if constexpr (sizeof(T) == 2) {
-                        const f32x2 lo = gelu_fast2(f32x2{v[0], v[1]}), hi = gelu_fast2(f32x2{v[2], v[3]});
-                        v = f32x4{lo[0], lo[1], hi[0], hi[1]};
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = tc_gelu(v[e]);
-                    }
-                    acc[ni][mi] = v;
-                }
-        } else if constexpr (EPI == TC_EPI_QKV_ROPE) {
-            if (section < 2) {
-                const float qs = section == 0 ? p.q_scale : 1.0f;
-                const int half = p.head_dim >> 1;
-                // this lane's 4 columns of n-tile ni are rotary pairs pi(ni) + fgrp*2 + {0,1}
-                const int tile_pos0 = (tm * BM) % p.T;
-                const bool recur = sizeof(T) == 2 && tile_pos0 + BM <= p.T;
-                // No sequence boundary inside the tile (recur): rows 16 apart differ by a fixed
-                // angle, so only the first row's cos/sin are gathered (a gather touches 16 table
-                // rows per load instruction, which is what makes it expensive) and the other seven
-                // follow by angle addition with the table's row 16; 7 steps keep f32 accuracy.
-                // One n-tile at a time keeps the live rotary state at 8 registers.
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const int pi = (((wn * 64 + ni * 16) % p.head_dim) >> 1) + fgrp * 2;
-                    if (recur) {
-                        const long row = (long)(tile_pos0 + wm * 128 + frow) * half + pi;
-                        f32x2 c = *reinterpret_cast<const f32x2 *>(p.rope_cos + row);
-                        f32x2 sn = *reinterpret_cast<const f32x2 *>(p.rope_sin + row);
-                        const f32x2 c16 = *reinterpret_cast<const f32x2 *>(p.rope_cos + 16L * half + pi);
-                        const f32x2 s16 = *reinterpret_cast<const f32x2 *>(p.rope_sin + 16L * half + pi);
-#pragma unroll
-                        for (int mi = 0; mi < 8; ++mi) {
-                            const f32x4 v = acc[ni][mi] * qs;
-                            acc[ni][mi] = f32x4{v[0] * c[0] - v[1] * sn[0], v[1] * c[0] + v[0] * sn[0],
-                                                v[2] * c[1] - v[3] * sn[1], v[3] * c[1] + v[2] * sn[1]};
-                            const f32x2 cn = c * c16 - sn * s16;
-                            sn = sn * c16 + c * s16;
-                            c = cn;
-                        }
-                    } else {
-#pragma unroll
-                        for (int mi = 0; mi < 8; ++mi) {
-                            const long row = (long)((mrow0 + mi * 16) % p.T) * half + pi;
-                            const f32x2 c = *reinterpret_cast<const f32x2 *>(p.rope_cos + row);
-                            const f32x2 sn = *reinterpret_cast<const f32x2 *>(p.rope_sin + row);
-                            const f32x4 v = acc[ni][mi] * qs;
-                            acc[ni][mi] = f32x4{v[0] * c[0] - v[1] * sn[0], v[1] * c[0] + v[0] * sn[0],
-                                                v[2] * c[1] - v[3] * sn[1], v[3] * c[1] + v[2] * sn[1]};
-                        }
-                    }
-                }
-            }
-        } else if constexpr (EPI == TC_EPI_BIAS_RESIDUAL && !kPreloadResidual) {
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const int m = mrow0 + mi * 16;
-                const float *rp = p.residual + (long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0;
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[ni][mi] = *reinterpret_cast<const f32x4 *>(rp + ni * 16) + acc[ni][mi];
-            }
-        }
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = mrow0 + mi * 16;
-            if (m < p.M) {
-                const long orow = (long)m * p.ldo + ncol0;
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const f32x4 v = acc[ni][mi];
-                    if constexpr (EPI == TC_EPI_BIAS_RESIDUAL || EPI == TC_EPI_PLAIN_F32 || sizeof(T) == 4) {
-                        *reinterpret_cast<f32x4 *>(p.out + (orow + ni * 16) * 4) = v;
-                    } else {
-                        u32x2 w;
-                        w[0] = tc_pack_bf16(v[0], v[1]);
-                        w[1] = tc_pack_bf16(v[2], v[3]);
-                        *reinterpret_cast<u32x2 *>(p.out + (orow + ni * 16) * 2) = w;
-                    }
-                }
-            }
-        }
+        epilogue256<T, EPI>(p, acc, tm, tn, mrow0, ncol0, wm, wn, frow, fgrp);
 #ifdef TC_GEMM_STAMPS
         TC_STAMP(e1);
         c_epi += e1 - e0;
@@ -685,12 +704,12 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
     GemmParams p = p0;
     if (big) {
         if constexpr (sizeof(T) == 2) {
-        static bool attr_set = false;   // benign race: the attribute call is idempotent
+        static bool attr_set = false;   // benign race: the attribute calls are idempotent
         auto kern = gemm256_kernel<T, EPI>;
+        const int lds = k256::LDS_BYTES;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               k256::LDS_BYTES);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256_kernel<T, EPI>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, k256::LDS_BYTES);
             if (e != hipSuccess) {
                 tc_set_error("tc_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
                 return TC_ELAUNCH;
@@ -722,7 +741,7 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
 #ifdef TC_GEMM_STAMPS
         p.stamps = g_stamps;
 #endif
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), k256::LDS_BYTES, stream, p);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
         }
     } else {
         static bool attr_set = false;
