@@ -285,3 +285,28 @@ def test_mlm_mask_follows_the_collator_arithmetic():
     out3, labels3, _ = TR.mlm_mask(torch.from_numpy(tok).to(DEV), torch.from_numpy(lens).to(DEV), seed=123)
     assert not np.array_equal(labels2.cpu().numpy(), labels) and np.array_equal(labels3.cpu().numpy(), labels)
     assert np.array_equal(out3.cpu().numpy(), out)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gradients_against_reference_fixture(golden_dir, dtype):
+    """HIP training step against gradients produced by the reference model itself
+    (tests/golden/tiny_grads.npz, made by tools/gen_golden_grads.py)."""
+    import os
+    g = np.load(os.path.join(golden_dir, "tiny_forward.npz"))
+    gr = np.load(os.path.join(golden_dir, "tiny_grads.npz"))
+    sd = seeded_state_dict(O.TINY, int(g["seed"]), perturb=True)
+    m = _model(O.TINY, sd, dtype)
+    out = m(torch.from_numpy(g["tokens"]).to(DEV), torch.from_numpy(g["species"]).to(DEV))
+    loss = TR.mlm_loss(out["logits"], torch.from_numpy(g["labels"]).to(DEV), out["struct_label_output"],
+                       torch.from_numpy(g["struct_labels"]).to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(gr["loss"])) <= (1e-4 if dtype == torch.float32 else 3e-2)
+    got = dict(m.named_parameters())
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+    for key in gr.files:
+        if key == "loss":
+            continue
+        k = key.replace("__", ".")
+        ref = torch.from_numpy(gr[key])
+        err = float((got[k].grad.float().cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-8)
+        assert err <= tol, (k, err)

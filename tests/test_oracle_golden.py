@@ -108,3 +108,26 @@ def test_schedule(golden_dir):
     vals = [O.warmup_cosine(s, g["warmup"], g["num_steps"]) for s in range(0, 120, 7)]
     assert vals == g["values"]
     assert O.warmup_cosine(0, 10, 100) == 0.1 and O.warmup_cosine(9, 10, 100) == 1.0
+
+
+def test_oracle_autograd_matches_reference_gradients(golden_dir):
+    """tests/golden/tiny_grads.npz: loss and every parameter gradient of the REFERENCE model on the
+    tiny batch (tools/gen_golden_grads.py).  The oracle's autograd must reproduce them: this pins
+    the checker used for all gradient parity tests."""
+    g = np.load(os.path.join(golden_dir, "tiny_forward.npz"))
+    gr = np.load(os.path.join(golden_dir, "tiny_grads.npz"))
+    sd = seeded_state_dict(O.TINY, int(g["seed"]), perturb=True)
+    with torch.enable_grad():
+        leaf = {k: v.clone().requires_grad_(v.is_floating_point() and "rope" not in k) for k, v in sd.items()}
+        out = O.forward(leaf, O.TINY, torch.from_numpy(g["tokens"]), torch.from_numpy(g["species"]), repr_layers=())
+        loss = O.mlm_loss(out["logits"], torch.from_numpy(g["labels"]), out["struct_label_output"],
+                          torch.from_numpy(g["struct_labels"]))
+        loss.backward()
+    assert abs(float(loss) - float(gr["loss"])) < 1e-6
+    names = [k for k in gr.files if k != "loss"]
+    assert len(names) == 48
+    for key in names:
+        k = key.replace("__", ".")
+        ref = gr[key]
+        got = leaf[k].grad.numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-7 + 1e-6 * np.abs(ref).max(), err_msg=k)
