@@ -92,7 +92,7 @@ def bench_train(args, world, rank, dev, dist_on):
     one micro-batch per GPU (pretraining.py:94-134 with accumulate_grad_batches = 1)."""
     import torch.distributed as dist
     from transcodon_amd import train as TR
-    from transcodon_amd.parallel import allreduce_grads
+    from transcodon_amd.parallel import GradientSync
     B, T = args.train_batch, args.train_seq_len
     model = ta.ProteinBertModel(ta.default_args(), ta.Alphabet.from_architecture("CodonModel"))
     ta.init_weights(model, seed=1236)
@@ -100,6 +100,7 @@ def bench_train(args, world, rank, dev, dist_on):
     model.check_indices = False
     flat = TR.FlatParameters(model)
     opt = TR.AdamW(flat, lr=2e-4, weight_decay=0.1)
+    flat.grad_sync = GradientSync(flat)       # per-layer all-reduce overlapped with the backward (no-op at N=1)
     struct_params = TR.structure_head_parameters(model)
     tok_np, sp_np, _, _, _ = synthetic_batch(B, T, seed=1236 + rank)
     rng = np.random.default_rng(1313 + rank)
@@ -114,8 +115,7 @@ def bench_train(args, world, rank, dev, dist_on):
         flat.zero_grad()
         out = model(tok, sp)
         loss = TR.mlm_loss(out["logits"], labels)        # structure labels are all -100 as shipped
-        loss.backward()
-        allreduce_grads(flat.grad)
+        loss.backward()                                  # includes the gradient mean over ranks
         opt.step(lr_factor=TR.warmup_cosine(i, 100, 10000), exclude=struct_params)
         return loss
 

@@ -399,6 +399,20 @@ int tc_encoder_backward(const tc_encoder_desc *desc, const tc_encoder_grads *gra
                         const float *dstruct_logits, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * tc_encoder_backward with a host callback for overlapping the data-parallel gradient exchange
+ * with the rest of the backward (what DDP's per-bucket hooks do for pretraining.py:243):
+ * ready(l, user) is called on the calling thread as soon as every kernel that writes the
+ * gradients of layer l (l = num_layers-1 ... 0) has been enqueued on `stream`, and ready(-1, user)
+ * once after the embedding / final LayerNorm / head gradients.  The callee typically records an
+ * event on `stream` and starts an all-reduce of that layer's gradient range on another stream.
+ */
+typedef void (*tc_grads_ready_fn)(int layer, void *user);
+int tc_encoder_backward_notify(const tc_encoder_desc *desc, const tc_encoder_grads *grads, const int32_t *tokens,
+                               const int32_t *species, int B, int T, const float *dlogits,
+                               const float *dstruct_logits, void *workspace, size_t workspace_bytes,
+                               tc_grads_ready_fn ready, void *user, void *stream);
+
+/*
  * The objective of pretraining.py:109-130 with its gradient:
  *   loss = CE_mean(logits, labels; ignore -100)
  *          + struct_weight * CE_mean(struct_logits, struct_labels; ignore -100)   if any struct label is set

@@ -310,3 +310,38 @@ def test_gradients_against_reference_fixture(golden_dir, dtype):
         ref = torch.from_numpy(gr[key])
         err = float((got[k].grad.float().cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-8)
         assert err <= tol, (k, err)
+
+
+def test_gradient_sync_callback_path_single_rank():
+    """The overlapped gradient exchange on one GPU: a one-rank process group (RCCL), collectives
+    forced on.  The per-layer callback path must leave exactly the gradients of the plain path,
+    and no_sync() must accumulate locally."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from transcodon_amd.parallel import GradientSync
+    cfg = O.TINY
+    sd = seeded_state_dict(cfg, 41, perturb=True)
+    tok, sp, labels, st = _batch(cfg, 2, 40, 3, pad_tail=(0, 9), struct=True)
+    a, b = _model(cfg, sd, torch.float32), _model(cfg, sd, torch.float32)
+    fa, fb = TR.FlatParameters(a), TR.FlatParameters(b)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        fb.grad_sync = GradientSync(fb)
+        fb.grad_sync.exchange_single = True
+        for m in (a, b):
+            out = m(tok.to(DEV), sp.to(DEV))
+            TR.mlm_loss(out["logits"], labels.to(DEV), out["struct_label_output"], st.to(DEV)).backward()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(fb.grad.cpu().numpy(), fa.grad.cpu().numpy(), rtol=1e-4, atol=1e-7)
+        assert float(fb.grad.abs().max()) > 0
+        with fb.grad_sync.no_sync():
+            out = b(tok.to(DEV), sp.to(DEV))
+            TR.mlm_loss(out["logits"], labels.to(DEV), out["struct_label_output"], st.to(DEV)).backward()
+        np.testing.assert_allclose(fb.grad.cpu().numpy(), 2 * fa.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    finally:
+        dist.destroy_process_group()

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from transcodon_amd.parallel import allreduce_grads, distributed_map, shard_range
+from transcodon_amd.parallel import GradientSync, allreduce_grads, distributed_map, shard_range
 
 
 def test_shard_range_partitions_exactly():
@@ -56,6 +56,38 @@ def _worker(rank, world, port, out):
         g = torch.full((5,), float(rank + 1))
         allreduce_grads(g)
         assert torch.allclose(g, torch.full((5,), 1.5))
+        # overlapped per-layer gradient mean on a packed flat store (CPU tensors, same code path
+        # as the GPU one minus the side stream)
+        class _Layout:
+            loff = [{"a": (8, 3), "b": (12, 4)}, {"a": (16, 5), "b": (24, 2)}]
+            hoff = {"st_bias": (0, 3), "st_bias2": (4, 3)}
+            total = 32
+
+        class _Store:
+            layout = _Layout()
+
+            def __init__(self):
+                self.grad = torch.arange(32, dtype=torch.float32) * (rank + 1)
+
+            def sync_shared_bias_grad(self):
+                self.grad[4:7] = self.grad[0:3]
+
+        store = _Store()
+        sync = GradientSync(store)
+        assert sync.layer_ranges == [(8, 16), (16, 32)] and sync.head_range == (0, 8)
+        with sync.no_sync():                      # a micro-batch inside an accumulation window
+            for layer in (1, 0, -1):
+                sync.on_ready(layer)
+            sync.finish()
+        local = torch.arange(32, dtype=torch.float32) * (rank + 1)
+        local[4:7] = local[0:3]
+        assert torch.equal(store.grad, local)
+        for layer in (1, 0, -1):
+            sync.on_ready(layer)
+        sync.finish()
+        want = torch.arange(32, dtype=torch.float32) * 1.5
+        want[4:7] = want[0:3]
+        assert torch.allclose(store.grad, want)
         out.put((rank, "ok"))
     finally:
         dist.destroy_process_group()

@@ -52,6 +52,9 @@ class EncoderGrads(C.Structure):
                 + [(n, vp) for n in HEAD_GRAD_FIELDS])
 
 
+GRADS_READY_FN = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
+
+
 class HipLibraryError(RuntimeError):
     pass
 
@@ -98,6 +101,8 @@ _SIGNATURES = {
                                            C.c_size_t, vp]),
     "tc_encoder_backward": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderGrads), vp, vp, C.c_int, C.c_int,
                                       vp, vp, vp, C.c_size_t, vp]),
+    "tc_encoder_backward_notify": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderGrads), vp, vp, C.c_int,
+                                             C.c_int, vp, vp, vp, C.c_size_t, vp, vp, vp]),
     "tc_mlm_loss": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, vp]),
     "tc_mlm_mask": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_double,
                               C.c_int, vp, C.c_int, vp]),

@@ -240,6 +240,14 @@ extern "C" int tc_encoder_backward(const tc_encoder_desc *d, const tc_encoder_gr
                                    const int32_t *species, int B, int T, const float *dlogits,
                                    const float *dstruct_logits, void *workspace, size_t workspace_bytes,
                                    void *stream) {
+    return tc_encoder_backward_notify(d, g, tokens, species, B, T, dlogits, dstruct_logits, workspace, workspace_bytes,
+                                      nullptr, nullptr, stream);
+}
+
+extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_encoder_grads *g, const int32_t *tokens,
+                                          const int32_t *species, int B, int T, const float *dlogits,
+                                          const float *dstruct_logits, void *workspace, size_t workspace_bytes,
+                                          tc_grads_ready_fn ready, void *user, void *stream) {
     TC_TRY(check_desc(d, "tc_encoder_backward"));
     TC_REQUIRE(g && g->layers && tokens && species && dlogits && workspace, "tc_encoder_backward: null operand");
     TC_REQUIRE(B > 0 && T > 0 && (long)B * T < (1L << 31) - 64, "tc_encoder_backward: bad batch B=%d T=%d", B, T);
@@ -322,8 +330,10 @@ extern "C" int tc_encoder_backward(const tc_encoder_desc *d, const tc_encoder_gr
                              1, stream));
         TC_TRY(tc_layernorm_bwd(TC_F32, sv.x_in, E, lw.ln1_g, w.t0, dx, 1, lg.ln1_g, lg.ln1_b, M, E, d->ln_eps,
                                 stream));
+        if (ready) ready(l, user);       // every kernel that writes layer l's gradients is enqueued
     }
     TC_TRY(tc_embed_bwd(tokens, species, dx, g->tok_table, g->species_table, B, T, E, d->vocab, d->n_species,
                         d->pad_idx, stream));
+    if (ready) ready(-1, user);          // embeddings, final LayerNorm and heads
     return TC_OK;
 }

@@ -69,3 +69,84 @@ def allreduce_grads(flat_grad: torch.Tensor, group=None) -> torch.Tensor:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
             flat_grad.div_(world)
     return flat_grad
+
+
+class GradientSync:
+    """Data-parallel gradient mean overlapped with the backward (the role of DDP's bucket hooks
+    in the reference, pretraining.py:243).
+
+    Attach to a packed ``train.FlatParameters`` store: ``store.grad_sync = GradientSync(store)``.
+    The backward (tc_encoder_backward_notify) reports every layer whose gradients are complete;
+    that layer's contiguous range of the flat gradient buffer is then all-reduced on a side
+    stream while the kernels of the layers below keep the compute stream busy.  The range holding
+    the embeddings, the final LayerNorm and the heads goes last.  ``finish()`` (called by the
+    backward) makes the compute stream wait for the exchanges and turns the sums into means.
+    Inside ``no_sync()`` nothing is exchanged: micro-batches of a gradient-accumulation step
+    only add up locally and the last one, outside the context, exchanges the total."""
+
+    def __init__(self, store, group=None):
+        if getattr(store, "layout", None) is None:
+            raise ValueError("GradientSync needs a FlatParameters store in the packed layout")
+        self.store, self.group = store, group
+        self.enabled = True
+        self.exchange_single = False      # also run the collectives in a one-rank group (tests)
+        starts = [min(o for o, _ in d.values()) for d in store.layout.loff] + [store.layout.total]
+        self.layer_ranges = [(starts[i], starts[i + 1]) for i in range(len(store.layout.loff))]
+        self.head_range = (0, starts[0])
+        self.side = torch.cuda.Stream(device=store.grad.device) if store.grad.is_cuda else None
+        self._pending = []
+        self.error = None
+
+    def world(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def active(self) -> bool:
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return self.enabled and (self.world() > 1 or self.exchange_single)
+
+    class _NoSync:
+        def __init__(self, owner):
+            self.owner = owner
+
+        def __enter__(self):
+            self.prev, self.owner.enabled = self.owner.enabled, False
+
+        def __exit__(self, *exc):
+            self.owner.enabled = self.prev
+
+    def no_sync(self):
+        return GradientSync._NoSync(self)
+
+    def on_ready(self, layer: int):
+        """Callback of the backward: gradients of ``layer`` (or of everything else for -1) are
+        complete in stream order."""
+        try:
+            if layer < 0:
+                self.store.sync_shared_bias_grad()
+            if not self.active():
+                return
+            b, e = self.head_range if layer < 0 else self.layer_ranges[layer]
+            bucket = self.store.grad[b:e]
+            if bucket.is_cuda:
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(bucket.device))
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(ready)
+                    work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending.append(work)
+        except Exception as exc:      # a ctypes callback cannot propagate: keep it for finish()
+            self.error = exc
+
+    def finish(self):
+        """Wait (in stream order) for the exchanges started by on_ready and divide by the world size."""
+        err, self.error = self.error, None
+        pending, self._pending = self._pending, []
+        for work in pending:
+            work.wait()
+        if err is not None:
+            raise err
+        if pending:
+            self.store.grad.div_(self.world())

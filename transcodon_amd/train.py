@@ -169,15 +169,23 @@ class EncoderTrainFunction(torch.autograd.Function):
         if struct is None:
             gp = _GradPack(model, dev)
             struct = gp.struct
-        check(_lib.load().tc_encoder_backward(
-            C.byref(ctx.pk["desc"]), C.byref(struct), ctx.tok32.data_ptr(), ctx.sp32.data_ptr(), B, T,
-            dlogits.data_ptr(), None if dstruct is None else dstruct.data_ptr(), ctx.ws.data_ptr(),
-            ctx.ws.numel(), _stream()), "tc_encoder_backward")
+        sync = getattr(store, "grad_sync", None) if gp is None else None
+        args = (C.byref(ctx.pk["desc"]), C.byref(struct), ctx.tok32.data_ptr(), ctx.sp32.data_ptr(), B, T,
+                dlogits.data_ptr(), None if dstruct is None else dstruct.data_ptr(), ctx.ws.data_ptr(),
+                ctx.ws.numel())
+        if sync is not None:
+            # per-layer notification: the gradient exchange of a finished layer overlaps the rest
+            cb = _lib.GRADS_READY_FN(lambda layer, _user: sync.on_ready(layer))
+            check(_lib.load().tc_encoder_backward_notify(*args, cb, None, _stream()), "tc_encoder_backward")
+            sync.finish()
+        else:
+            check(_lib.load().tc_encoder_backward(*args, _stream()), "tc_encoder_backward")
         params = train_parameters(model)
         if gp is None:
             # the kernels accumulated straight into the parameter store's gradient buffer (which
             # the parameters' .grad attributes view): nothing for autograd to add
-            store.sync_shared_bias_grad()
+            if sync is None:
+                store.sync_shared_bias_grad()
             return (None,) * (3 + len(params))
         grads = [g.to(p.dtype) if p.requires_grad else None for p, g in zip(params, gp.views)]
         return (None, None, None, *grads)
@@ -296,6 +304,7 @@ class FlatParameters:
             self._gviews = gviews
             self.grads_struct, self._grad_layers = self.layout.grads_struct(self.grad)
             self._shadow = {}
+            self.grad_sync = None         # parallel.GradientSync, when gradients are exchanged
             model._flat_store = self
             _lib.weights_epoch[0] += 1
             return
