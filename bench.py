@@ -159,7 +159,10 @@ def bench_train(args, world, rank, dev, dist_on):
                        "first_loss": round(float(losses[0]), 4), "last_loss": round(float(losses[-1]), 4)},
             "roofline": {"bound": "mfma", "kernel": "gemm kernels (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n,
+                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
+                         "traffic": pmc_traffic("r01_pmc_traffic_train.json"),
+                         "traffic_unit": "HBM bytes per GEMM launch (PMC pass of this command, committed under profiles/)",
+                         "launches": n,
                          "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
                          "whole_step_tflops": round(model_tflops, 2),
                          "whole_step_frac": round(model_tflops / PEAK_BF16_TFLOPS, 4)},
