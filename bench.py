@@ -161,6 +161,7 @@ def bench_train(args, world, rank, dev, dist_on):
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
                          "traffic": pmc_traffic("r01_pmc_traffic_train.json"),
+                         "mfma_busy_pmc": pmc_mfma_busy("r01_pmc_traffic_train.json"),
                          "traffic_unit": "HBM bytes per GEMM launch (PMC pass of this command, committed under profiles/)",
                          "launches": n,
                          "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
@@ -172,6 +173,18 @@ def bench_train(args, world, rank, dev, dist_on):
         print(json.dumps(result))
     if dist_on:
         dist.destroy_process_group()
+
+
+def pmc_mfma_busy(path, prefix="gemm"):
+    """Launch-weighted share of SIMD cycles with the matrix pipe busy, from the same committed pass."""
+    try:
+        with open(os.path.join(ROOT, "profiles", path)) as fh:
+            ks = json.load(fh)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    sel = [v for k, v in ks.items() if k.startswith(prefix) and "mfma_busy" in v]
+    n = sum(v["dispatches"] for v in sel)
+    return round(sum(v["mfma_busy"] * v["dispatches"] for v in sel) / n, 4) if n else None
 
 
 def pmc_traffic(path, prefix="gemm"):
@@ -197,7 +210,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("infer", "train"), default="infer",
                     help="infer: forward + decode (headline metric); train: masked-LM optimiser step")
-    ap.add_argument("--train-batch", type=int, default=32)
+    ap.add_argument("--train-batch", type=int, default=64)
     ap.add_argument("--train-seq-len", type=int, default=1024)
     args = ap.parse_args()
 
@@ -292,6 +305,7 @@ def main():
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
                          "traffic": pmc_traffic("r01_pmc_traffic_infer.json"),
+                         "mfma_busy_pmc": pmc_mfma_busy("r01_pmc_traffic_infer.json"),
                          "traffic_unit": "HBM bytes per GEMM launch (PMC pass of this command, committed under profiles/)",
                          "algorithmic_bytes_per_launch": round(gemm_bytes / max(n, 1)),
                          "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),

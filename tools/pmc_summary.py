@@ -31,6 +31,14 @@ def short(name):
     return base
 
 
+def mfma_busy(a, c):
+    """Fraction of SIMD-cycles with the matrix pipe busy: the SQ counter is summed over the chip's
+    1024 SIMDs, GRBM_GUI_ACTIVE over its 8 XCDs."""
+    busy = a["SQ_VALU_MFMA_BUSY_CYCLES"] / max(len(c["SQ_VALU_MFMA_BUSY_CYCLES"]), 1)
+    active = a["GRBM_GUI_ACTIVE"] / max(len(c["GRBM_GUI_ACTIVE"]), 1) / 8.0
+    return busy / (1024.0 * active) if active else 0.0
+
+
 def main(root):
     acc = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(lambda: defaultdict(set))
@@ -53,6 +61,9 @@ def main(root):
             wc = a["SQ_WAVE_CYCLES"]
             print("   -> share of wave cycles: WAIT_ANY %.3f  WAIT_INST_ANY %.3f  ACTIVE_INST_ANY %.3f" % (
                 a.get("SQ_WAIT_ANY", 0) / wc, a.get("SQ_WAIT_INST_ANY", 0) / wc, a.get("SQ_ACTIVE_INST_ANY", 0) / wc))
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in a and "GRBM_GUI_ACTIVE" in a:
+            print("   -> MFMA pipes busy %.3f of the time (MFMA_BUSY summed over 1024 SIMDs / (GUI_ACTIVE summed over 8 XCDs / 8))" %
+                  mfma_busy(a, calls[k]))
         if "FETCH_SIZE" in a or "WRITE_SIZE" in a:
             nf = max(len(calls[k].get("FETCH_SIZE", [])), 1)
             nw = max(len(calls[k].get("WRITE_SIZE", [])), 1)
@@ -68,6 +79,8 @@ def main(root):
                 nf, nw = len(calls[k]["FETCH_SIZE"]), len(calls[k]["WRITE_SIZE"])
                 out[k] = {"read_bytes": 2 * a["FETCH_SIZE"] * 1024 / nf, "write_bytes": a["WRITE_SIZE"] * 1024 / nw,
                           "dispatches": nf}
+                if "SQ_VALU_MFMA_BUSY_CYCLES" in a and "GRBM_GUI_ACTIVE" in a:
+                    out[k]["mfma_busy"] = round(mfma_busy(a, calls[k]), 4)
         json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per dispatch; "
                              "reads = 2 x FETCH_SIZE KiB (gfx950 correction)", "kernels": out},
                   open(sys.argv[2], "w"), indent=1, sort_keys=True)
