@@ -24,6 +24,7 @@
 // consecutive columns per lane, so that bias / GELU / residual / rotary arithmetic works on
 // contiguous columns and global accesses are 16 bytes.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -49,8 +50,10 @@ struct GemmParams {
     float q_scale;
     int gm;          // large-tile kernel: row panels per ordering group (1 = n-fastest)
     int gn;          // large-tile kernel: column panels per ordering group (tiles_n = no grouping)
+    int stagger;     // alternating kernel: start delay per workgroup class, in shader clocks
 #ifdef TC_GEMM_STAMPS
     unsigned long long *stamps;   // per workgroup: wait, issue, math, epilogue cycles (wave 0)
+    int nostore;                  // experiment: the large-tile epilogue skips its final stores
 #endif
 };
 
@@ -350,27 +353,42 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B (64 KiB)
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;     // 128 KiB
 }  // namespace k256
 
+// Row / column offset of accumulator tile (mi, ni) inside the wave's part of the 256 x 256 tile.
+// LAY 0: the wave owns one 128 x 64 block (rows mi*16, columns ni*16).  LAY 1: the wave owns a
+// 64 x 32 block in each quarter of the tile (row blocks 128 apart, column blocks 128 apart), which
+// is what lets one quarter of the accumulators depend on one half of each operand tile only.
+// LAY 2: as LAY 1, with the W rows of a pair of accumulator tiles interleaved in groups of four
+// (operand row i of tile nb is column (i >> 2) * 8 + nb * 4 + (i & 3) of the 32-column block), so
+// that a lane's 4 + 4 values of the pair are 8 consecutive output columns: bf16 results leave as
+// 16-byte stores, 64 contiguous bytes per output row and instruction instead of 32.
+template <int LAY> __device__ __forceinline__ constexpr int mi_off(int mi) {
+    return LAY ? (mi >> 2) * 128 + (mi & 3) * 16 : mi * 16;
+}
+template <int LAY> __device__ __forceinline__ constexpr int ni_off(int ni) {
+    return LAY == 2 ? (ni >> 1) * 128 + (ni & 1) * 4 : LAY == 1 ? (ni >> 1) * 128 + (ni & 1) * 16 : ni * 16;
+}
+
 // Accumulators of one 128 x 64 wave tile start at bias (+ residual): no bias registers are held
 // through the k-loop.  acc[ni][mi] = D[n][m] tiles of 16 x 16.
-template <typename T, int EPI>
+template <typename T, int EPI, int LAY = 0, int MI0 = 0, int MI1 = 8, int NI0 = 0, int NI1 = 4>
 __device__ __forceinline__ void init_acc256(const GemmParams &p, f32x4 (&acc)[4][8], int mrow0, int ncol0) {
     constexpr bool kPreloadResidual = EPI == TC_EPI_BIAS_RESIDUAL && sizeof(T) == 2;
     {
         f32x4 bias[4];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-            bias[ni] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + ncol0 + ni * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ni = NI0; ni < NI1; ++ni)
+            bias[ni] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + ncol0 + ni_off<LAY>(ni)) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
+        for (int mi = MI0; mi < MI1; ++mi) {
             if constexpr (kPreloadResidual) {
-                const int m = mrow0 + mi * 16;
+                const int m = mrow0 + mi_off<LAY>(mi);
                 const float *rp = p.residual + (long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0;
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[ni][mi] = *reinterpret_cast<const f32x4 *>(rp + ni * 16) + bias[ni];
+                for (int ni = NI0; ni < NI1; ++ni)
+                    acc[ni][mi] = *reinterpret_cast<const f32x4 *>(rp + ni_off<LAY>(ni)) + bias[ni];
             } else {
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = bias[ni];
+                for (int ni = NI0; ni < NI1; ++ni) acc[ni][mi] = bias[ni];
             }
         }
     }
@@ -379,38 +397,72 @@ __device__ __forceinline__ void init_acc256(const GemmParams &p, f32x4 (&acc)[4]
 
 // Epilogue of one wave tile.  Phase 1: arithmetic in place (its table loads are not queued
 // behind any store); phase 2: all stores.
-template <typename T, int EPI>
+template <typename T, int EPI, int LAY = 0, int MI0 = 0, int MI1 = 8, int NI0 = 0, int NI1 = 4>
 __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4][8], int tm, int tn, int mrow0,
-                                            int ncol0, int wm, int wn, int frow, int fgrp) {
+                                            int ncol0, int wm, int wn, int frow, int fgrp,
+                                            const char *bias_lds = nullptr) {
     using namespace k256;
     constexpr bool kPreloadResidual = EPI == TC_EPI_BIAS_RESIDUAL && sizeof(T) == 2;
     const int section = EPI == TC_EPI_QKV_ROPE ? (tn * BN) / p.E : 0;
+    if (bias_lds) {
+        // accumulators started at zero; the tile's 256 bias values are in this wave's LDS copy
+#pragma unroll
+        for (int ni = NI0; ni < NI1; ++ni) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(
+                bias_lds + (ncol0 - tn * BN + ni_off<LAY>(ni)) * 4);
+#pragma unroll
+            for (int mi = MI0; mi < MI1; ++mi) acc[ni][mi] += b;
+        }
+    }
     if constexpr (EPI == TC_EPI_BIAS_GELU_SAVE) {
         // pre-activation goes out first (kept for the backward pass), then GELU in place
+        if constexpr (LAY == 2) {
+            const int L = fgrp * 16 + frow;                  // lane exchange as for the final stores
+            const int pull = (((L & 3) << 4) | (L >> 2)) << 2;
+            const int mbase = tm * BM + wm * 64 + (L >> 2), nbase = tn * BN + wn * 32 + (L & 3) * 8;
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = mrow0 + mi * 16;
-            if (m < p.M) {
-                const long orow = (long)m * p.ldo + ncol0;
+            for (int mi = MI0; mi < MI1; ++mi) {
+                const int m = mbase + mi_off<LAY>(mi);
+                const long orow = (long)m * p.ldo + nbase;
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const f32x4 v = acc[ni][mi];
-                    u32x2 w;
+                for (int ni = NI0; ni < NI1; ni += 2) {
+                    const f32x4 v = acc[ni][mi], v2 = acc[ni + 1][mi];
+                    u32x4 w;
                     w[0] = tc_pack_bf16(v[0], v[1]);
                     w[1] = tc_pack_bf16(v[2], v[3]);
-                    *reinterpret_cast<u32x2 *>(p.out2 + (orow + ni * 16) * 2) = w;
+                    w[2] = tc_pack_bf16(v2[0], v2[1]);
+                    w[3] = tc_pack_bf16(v2[2], v2[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = (unsigned)__builtin_amdgcn_ds_bpermute(pull, (int)w[e]);
+                    if (m < p.M) *reinterpret_cast<u32x4 *>(p.out2 + (orow + ni_off<LAY>(ni)) * 2) = w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int mi = MI0; mi < MI1; ++mi) {
+                const int m = mrow0 + mi_off<LAY>(mi);
+                if (m < p.M) {
+                    const long orow = (long)m * p.ldo + ncol0;
+#pragma unroll
+                    for (int ni = NI0; ni < NI1; ++ni) {
+                        const f32x4 v = acc[ni][mi];
+                        u32x2 w;
+                        w[0] = tc_pack_bf16(v[0], v[1]);
+                        w[1] = tc_pack_bf16(v[2], v[3]);
+                        *reinterpret_cast<u32x2 *>(p.out2 + (orow + ni_off<LAY>(ni)) * 2) = w;
+                    }
                 }
             }
         }
     }
     if constexpr (EPI == TC_EPI_DGELU) {
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = mrow0 + mi * 16;
+        for (int mi = MI0; mi < MI1; ++mi) {
+            const int m = mrow0 + mi_off<LAY>(mi);
             const char *up = p.aux + ((long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0) * 2;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const u32x2 w = *reinterpret_cast<const u32x2 *>(up + ni * 32);
+            for (int ni = NI0; ni < NI1; ++ni) {
+                const u32x2 w = *reinterpret_cast<const u32x2 *>(up + ni_off<LAY>(ni) * 2);
                 f32x4 v = acc[ni][mi];
                 v[0] *= gelu_grad<true>(tc_bf16_lo(w[0]));
                 v[1] *= gelu_grad<true>(tc_bf16_hi(w[0]));
@@ -422,9 +474,9 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
     }
     if constexpr (EPI == TC_EPI_BIAS_GELU || EPI == TC_EPI_BIAS_GELU_SAVE) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = NI0; ni < NI1; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
+            for (int mi = MI0; mi < MI1; ++mi) {
                 f32x4 v = acc[ni][mi];
                 if constexpr (sizeof(T) == 2) {
                     const f32x2 lo = gelu_fast2(f32x2{v[0], v[1]}), hi = gelu_fast2(f32x2{v[2], v[3]});
@@ -448,27 +500,36 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
             // follow by angle addition with the table's row 16; 7 steps keep f32 accuracy.
             // One n-tile at a time keeps the live rotary state at 8 registers.
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int pi = (((wn * 64 + ni * 16) % p.head_dim) >> 1) + fgrp * 2;
+            for (int ni = NI0; ni < NI1; ++ni) {
+                const int pi = ((ncol0 - tn * BN + ni_off<LAY>(ni)) % p.head_dim) >> 1;
                 if (recur) {
-                    const long row = (long)(tile_pos0 + wm * 128 + frow) * half + pi;
+                    const long row = (long)(tile_pos0 + (LAY ? wm * 64 : wm * 128) + mi_off<LAY>(MI0) + frow) * half + pi;
                     f32x2 c = *reinterpret_cast<const f32x2 *>(p.rope_cos + row);
                     f32x2 sn = *reinterpret_cast<const f32x2 *>(p.rope_sin + row);
                     const f32x2 c16 = *reinterpret_cast<const f32x2 *>(p.rope_cos + 16L * half + pi);
                     const f32x2 s16 = *reinterpret_cast<const f32x2 *>(p.rope_sin + 16L * half + pi);
+                    // LAY 1: the step from row block 3 to row block 4 is 128 - 48 = 80 rows
+                    constexpr bool kJump = LAY >= 1 && MI0 < 4 && MI1 > 4;
+                    f32x2 c80 = c16, s80 = s16;
+                    if constexpr (kJump) {
+                        c80 = *reinterpret_cast<const f32x2 *>(p.rope_cos + 80L * half + pi);
+                        s80 = *reinterpret_cast<const f32x2 *>(p.rope_sin + 80L * half + pi);
+                    }
 #pragma unroll
-                    for (int mi = 0; mi < 8; ++mi) {
+                    for (int mi = MI0; mi < MI1; ++mi) {
                         const f32x4 v = acc[ni][mi] * qs;
                         acc[ni][mi] = f32x4{v[0] * c[0] - v[1] * sn[0], v[1] * c[0] + v[0] * sn[0],
                                             v[2] * c[1] - v[3] * sn[1], v[3] * c[1] + v[2] * sn[1]};
-                        const f32x2 cn = c * c16 - sn * s16;
-                        sn = sn * c16 + c * s16;
+                        const bool jump = kJump && mi == 3;
+                        const f32x2 cs = jump ? c80 : c16, ss = jump ? s80 : s16;
+                        const f32x2 cn = c * cs - sn * ss;
+                        sn = sn * cs + c * ss;
                         c = cn;
                     }
                 } else {
 #pragma unroll
-                    for (int mi = 0; mi < 8; ++mi) {
-                        const long row = (long)((mrow0 + mi * 16) % p.T) * half + pi;
+                    for (int mi = MI0; mi < MI1; ++mi) {
+                        const long row = (long)((mrow0 + mi_off<LAY>(mi)) % p.T) * half + pi;
                         const f32x2 c = *reinterpret_cast<const f32x2 *>(p.rope_cos + row);
                         const f32x2 sn = *reinterpret_cast<const f32x2 *>(p.rope_sin + row);
                         const f32x4 v = acc[ni][mi] * qs;
@@ -480,29 +541,75 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
         }
     } else if constexpr (EPI == TC_EPI_BIAS_RESIDUAL && !kPreloadResidual) {
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = mrow0 + mi * 16;
+        for (int mi = MI0; mi < MI1; ++mi) {
+            const int m = mrow0 + mi_off<LAY>(mi);
             const float *rp = p.residual + (long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                acc[ni][mi] = *reinterpret_cast<const f32x4 *>(rp + ni * 16) + acc[ni][mi];
+            for (int ni = NI0; ni < NI1; ++ni)
+                acc[ni][mi] = *reinterpret_cast<const f32x4 *>(rp + ni_off<LAY>(ni)) + acc[ni][mi];
         }
     }
+    constexpr bool kF32Out = EPI == TC_EPI_BIAS_RESIDUAL || EPI == TC_EPI_PLAIN_F32 || sizeof(T) == 4;
+#ifdef TC_GEMM_STAMPS
+    if (p.nostore) return;
+#endif
+    if constexpr (LAY >= 1) {
+        // In the accumulator layout the 16 lanes that are neighbours hold 16 different output
+        // rows, so a store instruction would reach memory as 64 separate 16-byte writes.  The
+        // 64 lanes exchange their 16 bytes first (lane 4 r + s takes the data of lane 16 s + r):
+        // four neighbouring lanes then write 64 contiguous bytes of one row.
+        const int L = fgrp * 16 + frow;
+        const int pull = (((L & 3) << 4) | (L >> 2)) << 2;
+        const int trow = L >> 2, tseg = L & 3;
+        const int mbase = tm * BM + wm * 64, nbase = tn * BN + wn * 32 + tseg * (LAY == 2 ? 8 : 4);
+        auto exchange = [&](u32x4 w) {
+            u32x4 o;
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        const int m = mrow0 + mi * 16;
-        if (m < p.M) {
-            const long orow = (long)m * p.ldo + ncol0;
+            for (int e = 0; e < 4; ++e) o[e] = (unsigned)__builtin_amdgcn_ds_bpermute(pull, (int)w[e]);
+            return o;
+        };
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const f32x4 v = acc[ni][mi];
-                if constexpr (EPI == TC_EPI_BIAS_RESIDUAL || EPI == TC_EPI_PLAIN_F32 || sizeof(T) == 4) {
-                    *reinterpret_cast<f32x4 *>(p.out + (orow + ni * 16) * 4) = v;
-                } else {
-                    u32x2 w;
+        for (int mi = MI0; mi < MI1; ++mi) {
+            const int m = mbase + mi_off<LAY>(mi) + trow;
+            const long orow = (long)m * p.ldo + nbase;
+            if constexpr (LAY == 2 && !kF32Out) {
+#pragma unroll
+                for (int ni = NI0; ni < NI1; ni += 2) {
+                    const f32x4 v = acc[ni][mi], v2 = acc[ni + 1][mi];
+                    u32x4 w;
                     w[0] = tc_pack_bf16(v[0], v[1]);
                     w[1] = tc_pack_bf16(v[2], v[3]);
-                    *reinterpret_cast<u32x2 *>(p.out + (orow + ni * 16) * 2) = w;
+                    w[2] = tc_pack_bf16(v2[0], v2[1]);
+                    w[3] = tc_pack_bf16(v2[2], v2[3]);
+                    w = exchange(w);
+                    if (m < p.M) *reinterpret_cast<u32x4 *>(p.out + (orow + ni_off<LAY>(ni)) * 2) = w;
+                }
+            } else {
+                static_assert(kF32Out, "bf16 results use the interleaved column order");
+#pragma unroll
+                for (int ni = NI0; ni < NI1; ++ni) {
+                    const u32x4 w = exchange(__builtin_bit_cast(u32x4, acc[ni][mi]));
+                    if (m < p.M) *reinterpret_cast<u32x4 *>(p.out + (orow + ni_off<LAY>(ni)) * 4) = w;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mi = MI0; mi < MI1; ++mi) {
+            const int m = mrow0 + mi_off<LAY>(mi);
+            if (m < p.M) {
+                const long orow = (long)m * p.ldo + ncol0;
+#pragma unroll
+                for (int ni = NI0; ni < NI1; ++ni) {
+                    const f32x4 v = acc[ni][mi];
+                    if constexpr (kF32Out) {
+                        *reinterpret_cast<f32x4 *>(p.out + (orow + ni_off<LAY>(ni)) * 4) = v;
+                    } else {
+                        u32x2 w;
+                        w[0] = tc_pack_bf16(v[0], v[1]);
+                        w[1] = tc_pack_bf16(v[2], v[3]);
+                        *reinterpret_cast<u32x2 *>(p.out + (orow + ni_off<LAY>(ni)) * 2) = w;
+                    }
                 }
             }
         }
@@ -692,6 +799,328 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 }
 
 // =============================================================================================
+// 256 x 256 tile, 8 waves, persistent, two wave groups in alternation
+// =============================================================================================
+// Same tile and MFMA operand order as gemm256_kernel; what differs is the schedule.  The two waves
+// that share a SIMD (wave w and w + 4: row group 0 and 1) run half a phase apart: while one issues
+// its 16 MFMAs of a phase, the other issues that phase's LDS reads and LDS-DMA loads, so the matrix
+// pipe never waits behind the same wave's memory instructions.
+//
+// A k-tile (64 k) is four half-tiles of 128 rows x 128 bytes: A0, A1 (tile rows 0..127, 128..255)
+// and B0, B1 (tile columns likewise).  A wave owns a 64 x 32 block in each quarter of the output
+// tile, so quarter (mq, nq) needs only A{mq} and B{nq}.  Phases of k-tile g (LDS buffer g & 1):
+//   0: read B0 (4 x 16 B), A0 (8)   stage A1 of k-tile g+1      math quarter (0,0)
+//   1: read B1 (4)                  stage B0 of k-tile g+2      math (0,1)
+//   2: read A1 (8)                  stage A0 of k-tile g+2      math (1,1)
+//   3: -                            stage B1 of k-tile g+2      math (1,0)
+// Every slot is restaged at least two phases after its last read, except B0 (read in phase 0,
+// restaged in phase 1): its four reads are issued first and retired (lgkmcnt(8)) before the
+// phase's first barrier.  The vector-memory counter retires in issue order, so the one wait of a
+// k-tile, vmcnt(6) in phase 3, leaves exactly the three half-tiles of k-tile g+2 in flight and
+// guarantees all of k-tile g+1; the two barriers that follow it publish that to every wave.
+namespace k256x {
+constexpr int BM = 256, BN = 256;
+constexpr int HALF_BYTES = 128 * 128;           // one half-tile (16 KiB)
+constexpr int DBUF_BYTES = 4 * HALF_BYTES;      // A0 A1 B0 B1
+constexpr int SLOT_A0 = 0, SLOT_A1 = HALF_BYTES, SLOT_B0 = 2 * HALF_BYTES, SLOT_B1 = 3 * HALF_BYTES;
+constexpr int BIAS_BYTES = 2 * 8 * 1024;        // per wave and tile parity: 256 floats
+constexpr int LDS_BYTES = 2 * DBUF_BYTES + BIAS_BYTES;   // 144 KiB
+}  // namespace k256x
+
+constexpr bool piecewise_epilogue(int epi) {
+    return epi == TC_EPI_BIAS || epi == TC_EPI_BIAS_GELU || epi == TC_EPI_BIAS_GELU_SAVE || epi == TC_EPI_PLAIN_F32;
+}
+
+#define TC_XBAR()                                  \
+    do {                                           \
+        __builtin_amdgcn_sched_barrier(0);         \
+        __builtin_amdgcn_s_barrier();              \
+        __builtin_amdgcn_sched_barrier(0);         \
+    } while (0)
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
+    using namespace k256x;
+    static_assert(sizeof(T) == 2, "bf16 only");
+    // Epilogues that read nothing from global memory (bias comes through LDS) run inside phase 0
+    // of the next tile's first k-tile, after that phase's LDS-DMA issue and before its LDS reads:
+    // nothing then waits for their stores.  The others run as one block between two tiles.
+    constexpr bool kPiece = piecewise_epilogue(EPI);
+    // bf16 results use the interleaved column order (16-byte stores); f32 results are 16 bytes
+    // per lane and accumulator tile already
+    constexpr int kLay = (EPI == TC_EPI_BIAS_RESIDUAL || EPI == TC_EPI_PLAIN_F32) ? 1 : 2;
+    constexpr int kTileStores = EPI == TC_EPI_BIAS_GELU_SAVE ? 32 : (kLay == 2 ? 16 : 32);   // store instructions per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wid >> 2, wc = wid & 3;                 // row group (= alternation group), column
+    const int frow = lane & 15, fgrp = lane >> 4;
+
+    // tile ownership: as in gemm256_kernel
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int cls = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int per_class = (gridDim.x + 7 - cls) >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int first = cls < r ? cls * (q + 1) : r * (q + 1) + (cls - r) * q;
+    const int count = q + (cls < r ? 1 : 0);
+    const int my_count = count > j ? (count - j + per_class - 1) / per_class : 0;
+    auto tile_coords = [&](int local, int &tm, int &tn) {
+        const int tile = first + j + local * per_class;
+        const int per_group = p.gm * p.tiles_n;
+        const int grp = tile / per_group, loc = tile - grp * per_group;
+        const int rows_here = min(p.gm, p.tiles_m - grp * p.gm);
+        tn = loc / rows_here;
+        tm = grp * p.gm + (loc - tn * rows_here);
+    };
+    if (my_count == 0) return;
+
+    // ---- staging: a half-tile is 16 pieces of 8 rows x 128 B; this wave moves pieces 2 wid, 2 wid + 1
+    // The 16-byte chunk c of row r sits at chunk position c ^ key(r) of its LDS row.  A rows:
+    // key = r & 7.  W rows, interleaved column order: key = (r & 3) | ((r >> 1) & 4), which is
+    // what keeps the 8 rows one fragment read touches per cycle ({0..3, 8..11} + const) apart.
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    unsigned a1_src[2];                          // cursor 1 (k-tile g+1): A1
+    unsigned b0_src[2], a0_src[2], b1_src[2];    // cursor 2 (k-tile g+2): B0, A0, B1
+    auto a_src_of = [&](int tm, int h, int i) -> unsigned {
+        int gm = tm * BM + h * 128 + (wid * 2 + i) * 8 + srow;
+        gm = gm < p.M ? gm : p.M - 1;
+        return (unsigned)gm * (unsigned)p.lda_bytes + schunk * 16;
+    };
+    auto b_src_of = [&](int tn, int h, int i) -> unsigned {
+        // row (2 wid + i) * 8 + srow of the half-tile: bit 3 of the row is i
+        const int chunk = kLay == 2 ? (lane & 7) ^ ((srow & 3) | (i << 2)) : schunk;
+        return (unsigned)(tn * BN + h * 128 + (wid * 2 + i) * 8 + srow) * (unsigned)p.ldw_bytes + chunk * 16;
+    };
+    auto set_c1 = [&](int local) {
+        int tm, tn;
+        tile_coords(local, tm, tn);
+        a1_src[0] = a_src_of(tm, 1, 0); a1_src[1] = a_src_of(tm, 1, 1);
+    };
+    auto set_c2 = [&](int local) {
+        int tm, tn;
+        tile_coords(local, tm, tn);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            b0_src[i] = b_src_of(tn, 0, i);
+            a0_src[i] = a_src_of(tm, 0, i);
+            b1_src[i] = b_src_of(tn, 1, i);
+        }
+    };
+    auto stage_half = [&](int slot_off, const char *base, const unsigned (&src)[2], unsigned koff) {
+        char *dst = smem + slot_off + wid * 2048;
+        glds16(base + (src[0] + koff), dst);
+        glds16(base + (src[1] + koff), dst + 1024);
+    };
+    // this wave's private copy of a tile's 256 bias values, two tiles deep
+    const bool lds_bias = kPiece && p.bias != nullptr;
+    auto bias_slot = [&](int local) -> char * { return smem + 2 * DBUF_BYTES + ((local & 1) * 8 + wid) * 1024; };
+    auto stage_bias = [&](int local) {
+        int tm, tn;
+        tile_coords(local, tm, tn);
+        glds16(reinterpret_cast<const char *>(p.bias + tn * BN + lane * 4), bias_slot(local));
+    };
+
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ((ks * 4 + fgrp) ^ (frow & 7)) << 4;
+        a_off[ks] = (wr * 64 + frow) * 128 + c;     // + i * 2048 inside half-tile A{mq}
+        if constexpr (kLay == 2) {                  // + nb * 512: operand row frow of tile nb
+            const int brow = (frow >> 2) * 8 + (frow & 3);
+            const int key = (frow & 3) | (((frow >> 2) & 1) << 2);
+            b_off[ks] = (wc * 32 + brow) * 128 + (((ks * 4 + fgrp) ^ key) << 4);
+        } else {
+            b_off[ks] = (wc * 32 + frow) * 128 + c; // + nb * 2048 inside half-tile B{nq}
+        }
+    }
+
+    if (p.stagger > 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long span = (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned)p.stagger;
+        while (__builtin_amdgcn_s_memtime() - t0 < span) __builtin_amdgcn_s_sleep(32);
+    }
+    // ---- prologue: all of k-tile 0, and B0 A0 B1 of k-tile 1 (the host guarantees nk >= 2) ----
+    set_c1(0);
+    set_c2(0);
+    if (lds_bias) stage_bias(0);
+    stage_half(SLOT_B0, p.W, b0_src, 0);
+    stage_half(SLOT_A0, p.A, a0_src, 0);
+    stage_half(SLOT_B1, p.W, b1_src, 0);
+    stage_half(SLOT_A1, p.A, a1_src, 0);
+    stage_half(DBUF_BYTES + SLOT_B0, p.W, b0_src, 128);
+    stage_half(DBUF_BYTES + SLOT_A0, p.A, a0_src, 128);
+    stage_half(DBUF_BYTES + SLOT_B1, p.W, b1_src, 128);
+    int c1_tile = 0, c1_k = 1;                   // next A1 to stage
+    int c2_tile = 0, c2_k = 2;                   // next B0 A0 B1 to stage
+    if (c2_k == p.nk) { c2_k = 0; c2_tile = 1; if (c2_tile < my_count) set_c2(c2_tile); }
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    TC_XBAR();
+    if (wr == 1) TC_XBAR();                       // row group 1 runs half a phase behind
+
+    f32x4 acc[4][8];                              // [ni][mi], D[n][m]
+    if constexpr (kPiece) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // epilogue of tile `local` (bias from this wave's LDS copy), accumulators back to zero
+    auto finish_tile = [&](int local) {
+        int tm, tn;
+        tile_coords(local, tm, tn);
+        const int mrow0 = tm * BM + wr * 64 + frow, ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);
+        epilogue256<T, EPI, kLay>(p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp,
+                               lds_bias ? bias_slot(local) : nullptr);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto tile_full = [&](int local) {
+        int tm, tn;
+        tile_coords(local, tm, tn);
+        return tm * BM + BM <= p.M;
+    };
+
+#ifdef TC_GEMM_STAMPS
+    unsigned long long c_kt[24] = {}, c_epi = 0;
+    TC_STAMP(k_begin);
+#endif
+    int g = 0;
+    for (int t = 0; t < my_count; ++t) {
+        int tm, tn;
+        tile_coords(t, tm, tn);
+        const int mrow0 = tm * BM + wr * 64 + frow;           // + mi_off<1>(mi)
+        const int ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);     // + ni_off<kLay>(ni)
+        if constexpr (!kPiece) init_acc256<T, EPI, kLay>(p, acc, mrow0, ncol0);
+        const bool prev_full = kPiece && t > 0 && tile_full(t - 1);
+
+        for (int kt = 0; kt < p.nk; ++kt, ++g) {
+            const int cur = (g & 1) * DBUF_BYTES, nxt = DBUF_BYTES - cur;
+            const char *sb = smem + cur;
+            const bool after = kPiece && kt == 0 && t > 0;   // the epilogue of tile t-1 is pending
+            TC_STAMP(s0);
+            f32x4 bq[2][2][2];                   // [nq][column block][k-step]
+            f32x4 af[4][2];                      // [row block][k-step] of the current mq
+
+            auto math = [&](int mq, int nq) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[nq * 2 + nb][mq * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, bq[nq][nb][ks]), __builtin_bit_cast(bf16x8, af[i][ks]),
+                                acc[nq * 2 + nb][mq * 4 + i], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            };
+            auto read_b = [&](int nq) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        bq[nq][nb][ks] = *reinterpret_cast<const f32x4 *>(
+                            sb + (nq ? SLOT_B1 : SLOT_B0) + b_off[ks] + nb * (kLay == 2 ? 512 : 2048));
+            };
+            auto read_a = [&](int mq) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        af[i][ks] = *reinterpret_cast<const f32x4 *>(
+                            sb + (mq ? SLOT_A1 : SLOT_A0) + a_off[ks] + i * 2048);
+            };
+
+            // Order inside a phase: LDS-DMA issue, then (first k-tile only) the previous tile's
+            // epilogue, while no operand fragment is live, then the LDS reads.
+            // ---- phase 0 ----
+            if (lds_bias && kt == 1 && t + 1 < my_count) stage_bias(t + 1);
+            if (c1_tile < my_count) {
+                stage_half(nxt + SLOT_A1, p.A, a1_src, (unsigned)c1_k * 128u);
+                if (++c1_k == p.nk) { c1_k = 0; if (++c1_tile < my_count) set_c1(c1_tile); }
+            }
+            if constexpr (kPiece) {
+                if (after) {
+                    TC_STAMP(e0);
+                    finish_tile(t - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#ifdef TC_GEMM_STAMPS
+                    TC_STAMP(e1);
+                    c_epi += e1 - e0;
+#endif
+                }
+            }
+            read_b(0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(0);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            TC_XBAR();
+            math(0, 0);
+            TC_XBAR();
+            // ---- phase 1 ----
+            const bool more = c2_tile < my_count;
+            const unsigned koff2 = (unsigned)c2_k * 128u;
+            if (more) stage_half(cur + SLOT_B0, p.W, b0_src, koff2);
+            read_b(1);
+            TC_XBAR();
+            math(0, 1);
+            TC_XBAR();
+            // ---- phase 2 ----
+            if (more) stage_half(cur + SLOT_A0, p.A, a0_src, koff2);
+            read_a(1);
+            TC_XBAR();
+            math(1, 1);
+            TC_XBAR();
+            // ---- phase 3 ----
+            // The wait leaves in flight what was issued after this k-tile's A1: three half-tiles,
+            // plus, in a tile's first k-tile, the previous tile's stores (when none of its rows
+            // was masked, so that every store instruction was issued; the counter holds 63).
+            if (more) {
+                stage_half(cur + SLOT_B1, p.W, b1_src, koff2);
+                if (++c2_k == p.nk) { c2_k = 0; if (++c2_tile < my_count) set_c2(c2_tile); }
+                if (after && prev_full) {
+                    if constexpr (kTileStores == 32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            TC_XBAR();
+            math(1, 0);
+            TC_XBAR();
+#ifdef TC_GEMM_STAMPS
+            TC_STAMP(s1);
+#pragma unroll
+            for (int i = 0; i < 24; ++i) if (i == (kt < 23 ? kt : 23)) c_kt[i] += s1 - s0;
+#endif
+        }
+        if constexpr (!kPiece) {
+            TC_STAMP(e0);
+            epilogue256<T, EPI, kLay>(p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp);
+#ifdef TC_GEMM_STAMPS
+            TC_STAMP(e1);
+            c_epi += e1 - e0;
+#endif
+        }
+    }
+#ifdef TC_GEMM_STAMPS
+    if (p.stamps && (threadIdx.x == 0 || threadIdx.x == 256)) {
+        TC_STAMP(k_end);
+        unsigned long long *o = p.stamps + (blockIdx.x * 2 + (threadIdx.x >> 8)) * 32;
+        for (int i = 0; i < 24; ++i) o[i] = c_kt[i];
+        o[24] = c_epi; o[25] = k_end - k_begin; o[26] = my_count;
+    }
+#endif
+    if constexpr (kPiece) finish_tile(my_count - 1);
+    if (wr == 0) TC_XBAR();                       // pairs with row group 1's last barrier
+}
+
+// =============================================================================================
 // host side
 // =============================================================================================
 int g_num_cus = 0;
@@ -740,8 +1169,26 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
         }
 #ifdef TC_GEMM_STAMPS
         p.stamps = g_stamps;
+        { const char *e = getenv("TC_GEMM_NOSTORE"); p.nostore = e ? atoi(e) : 0; }
 #endif
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+        { const char *e = getenv("TC_GEMM_STAGGER"); p.stagger = e ? atoi(e) * p.nk : 0; }
+        static int alt = -1;            // TC_GEMM_ALT=0 selects the single-group schedule
+        if (alt < 0) { const char *e = getenv("TC_GEMM_ALT"); alt = e ? atoi(e) != 0 : 1; }
+        if (alt) {
+            static bool attr_set_x = false;
+            if (!attr_set_x) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256x_kernel<T, EPI>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, k256x::LDS_BYTES);
+                if (e != hipSuccess) {
+                    tc_set_error("tc_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                    return TC_ELAUNCH;
+                }
+                attr_set_x = true;
+            }
+            hipLaunchKernelGGL((gemm256x_kernel<T, EPI>), dim3(grid), dim3(512), k256x::LDS_BYTES, stream, p);
+        } else {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+        }
         }
     } else {
         static bool attr_set = false;
