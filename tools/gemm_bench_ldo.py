@@ -35,12 +35,12 @@ if "out_bf16" in which:
         b = torch.randn(N, device=dev) * 0.1
         for pad in (0, 64, 128, 1024):
             buf = torch.empty(M, N + pad, device=dev, dtype=torch.bfloat16)
-
-            def run():
-                assert lib.tc_gemm(1, _lib.EPI_BIAS, a.data_ptr(), K, w.data_ptr(), b.data_ptr(), None,
-                                   buf.data_ptr(), N + pad, M, N, K, 1.0, None, None, 0, 0, strm) == 0
-            us = timeit(run)
-            print(f"bf16 out N={N} K={K} ldo={N + pad}: {us:8.1f} us {2 * M * N * K / us / 1e6:8.1f} TF/s", flush=True)
+            for epi, name in ((_lib.EPI_BIAS, "bias"), (_lib.EPI_BIAS_GELU, "gelu")):
+                def run():
+                    assert lib.tc_gemm(1, epi, a.data_ptr(), K, w.data_ptr(), b.data_ptr(), None,
+                                       buf.data_ptr(), N + pad, M, N, K, 1.0, None, None, 0, 0, strm) == 0
+                us = timeit(run)
+                print(f"bf16 out {name} N={N} K={K} ldo={N + pad}: {us:8.1f} us {2 * M * N * K / us / 1e6:8.1f} TF/s", flush=True)
 if "out_f32" in which:
     for (N, K) in [(768, 768), (768, 3072)]:
         a = torch.randn(M, K, device=dev).bfloat16()

@@ -9,7 +9,8 @@ struct Workspace {
     float *x;          // residual stream f32 [M,E]
     void *h;           // LayerNorm output / attention output [M,E] (dtype)
     void *qkv;         // [M,3E] (dtype)
-    void *mid;         // [M,max(F,2E)] (dtype)
+    void *mid;         // [M,max(F,2E)] (dtype), rows ld_mid elements apart
+    int ld_mid;
     uint8_t *pad;      // [M]
     uint64_t *words;   // [B, ceil(T/64)]
     size_t total;
@@ -29,7 +30,11 @@ Workspace carve(const tc_encoder_desc *d, int B, int T, char *base) {
     w.x = reinterpret_cast<float *>(take(M * d->E * 4));
     w.h = take(M * d->E * esz);
     w.qkv = take(M * 3 * d->E * esz);
-    w.mid = take(M * wide * esz);
+    // Rows of the FFN intermediate are padded by 128 bytes: with a row stride of 6144 bytes (F =
+    // 3072 in bf16) the stores of the fc1 epilogue run at a fraction of their normal rate on
+    // this memory system (measured: 672 us against 579 us for the 131072 x 3072 x 768 GEMM).
+    w.ld_mid = (int)wide + 64;
+    w.mid = take(M * (size_t)w.ld_mid * esz);
     w.pad = reinterpret_cast<uint8_t *>(take(M));
     w.words = reinterpret_cast<uint64_t *>(take((size_t)B * ((T + 63) / 64) * 8));
     w.total = off;
@@ -119,9 +124,9 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
         TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.h, E, lw.w_o, lw.b_o, w.x, w.x, E, M, E, E, 0.f, nullptr,
                        nullptr, 0, 0, stream));
         TC_TRY(ln(lw.ln2_g, lw.ln2_b, nullptr));
-        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_GELU, w.h, E, lw.w_fc1, lw.b_fc1, nullptr, w.mid, F, M, F, E, 0.f,
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_GELU, w.h, E, lw.w_fc1, lw.b_fc1, nullptr, w.mid, w.ld_mid, M, F, E, 0.f,
                        nullptr, nullptr, 0, 0, stream));
-        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.mid, F, lw.w_fc2, lw.b_fc2, w.x, w.x, E, M, E, F, 0.f,
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.x, w.x, E, M, E, F, 0.f,
                        nullptr, nullptr, 0, 0, stream));
         if (l + 1 < d->num_layers) TC_TRY(save_rep(l + 1));
     }
@@ -140,12 +145,12 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
         }
     }
     const int nheads = struct_logits ? 2 : 1;
-    TC_TRY(tc_gemm(dt, TC_EPI_BIAS_GELU, w.h, E, d->w_heads, d->b_heads, nullptr, w.mid, nheads * E, M,
+    TC_TRY(tc_gemm(dt, TC_EPI_BIAS_GELU, w.h, E, d->w_heads, d->b_heads, nullptr, w.mid, w.ld_mid, M,
                    nheads * E, E, 0.f, nullptr, nullptr, 0, 0, stream));
-    TC_TRY(tc_head_logits_fwd(dt, w.mid, nheads * E, 0, d->lm_ln_g, d->lm_ln_b, d->tok_table, d->lm_bias,
+    TC_TRY(tc_head_logits_fwd(dt, w.mid, w.ld_mid, 0, d->lm_ln_g, d->lm_ln_b, d->tok_table, d->lm_bias,
                               logits, M, E, d->vocab, d->ln_eps, stream));
     if (struct_logits)
-        TC_TRY(tc_head_logits_fwd(dt, w.mid, nheads * E, E, d->st_ln_g, d->st_ln_b, d->st_w, d->st_bias,
+        TC_TRY(tc_head_logits_fwd(dt, w.mid, w.ld_mid, E, d->st_ln_g, d->st_ln_b, d->st_w, d->st_bias,
                                   struct_logits, M, E, d->n_struct, d->ln_eps, stream));
     return TC_OK;
 }

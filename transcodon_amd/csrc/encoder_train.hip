@@ -33,7 +33,8 @@ struct TrainWs {
     // backward temporaries
     float *t0, *t1;      // f32 [M,E]
     void *dyb;           // dtype [M,E]
-    void *wide;          // dtype [M,max(F,3E)]
+    void *wide;          // dtype [M,max(F + 64,3E)]; F-wide contents use rows ld_f elements apart
+    int ld_f;            // row stride of every [M,F] activation: F + 64
     void *tr_a;          // dtype [max(F,3E), Mp]
     void *tr_b;          // dtype [max(F,E), Mp]
     void *wt;            // dtype transposed weight, max(F*E, 3E*E)
@@ -65,9 +66,13 @@ TrainWs carve(const tc_encoder_desc *d, int B, int T, char *base) {
     const size_t M = (size_t)B * T, E = d->E, F = d->F;
     const size_t esz = d->dtype == TC_BF16 ? 2 : 4;
     const size_t Mp = (M + 63) / 64 * 64;
-    const size_t wide = F > 3 * E ? F : 3 * E;
+    // [M,F] activations keep their rows 128 bytes further apart than F elements: a row stride of
+    // 6144 bytes (F = 3072, bf16) slows the stores of the GEMM epilogues that write them.
+    const size_t ldf = F + 64;
+    const size_t wide = ldf > 3 * E ? ldf : 3 * E;
     const int nk = (int)(Mp / (128 / esz));
     TrainWs w{};
+    w.ld_f = (int)ldf;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         char *p = base ? base + off : nullptr;
@@ -83,8 +88,8 @@ TrainWs carve(const tc_encoder_desc *d, int B, int T, char *base) {
         s.lse = reinterpret_cast<float *>(take((size_t)B * d->H * T * 4));
         s.x_mid = reinterpret_cast<float *>(take(M * E * 4));
         s.h2 = take(M * E * esz);
-        s.u = take(M * F * esz);
-        s.mid = take(M * F * esz);
+        s.u = take(M * ldf * esz);
+        s.mid = take(M * ldf * esz);
     }
     w.x = reinterpret_cast<float *>(take(M * E * 4));
     w.hf = take(M * E * esz);
@@ -135,9 +140,10 @@ int check_desc(const tc_encoder_desc *d, const char *who) {
     } while (0)
 
 // dW[n_out, n_in] += dY^T X with dY [M, n_out] (element type in_dt) and X [M, n_in] (dtype dt);
-// dbias[n_out] += column sums of dY.  dy_rowmajor (optional) receives dY converted to dt.
-int linear_wgrad(const tc_encoder_desc *d, TrainWs &w, int in_dt, const void *dy, void *dy_rowmajor,
-                 const void *x, int M, int n_out, int n_in, float *dW, float *dbias, void *stream) {
+// dbias[n_out] += column sums of dY.  dy_rowmajor (optional, dense) receives dY converted to dt.
+// ld_dy / ld_x: row strides of dY and X in elements.
+int linear_wgrad(const tc_encoder_desc *d, TrainWs &w, int in_dt, const void *dy, int ld_dy, void *dy_rowmajor,
+                 const void *x, int ld_x, int M, int n_out, int n_in, float *dW, float *dbias, void *stream) {
     const int dt = d->dtype;
     const int esz = dt == TC_BF16 ? 2 : 4;
     const int Mp = (M + 63) / 64 * 64;
@@ -149,15 +155,16 @@ int linear_wgrad(const tc_encoder_desc *d, TrainWs &w, int in_dt, const void *dy
         const void *dyb = dy;
         if (in_dt == TC_F32) {
             TC_REQUIRE(dy_rowmajor != nullptr, "linear_wgrad: f32 gradient needs a bf16 staging buffer");
-            TC_TRY(tc_colsum(TC_F32, dy, n_out, dy_rowmajor, n_out, dbias, M, n_out, stream));
+            TC_TRY(tc_colsum(TC_F32, dy, ld_dy, dy_rowmajor, n_out, dbias, M, n_out, stream));
             dyb = dy_rowmajor;
+            ld_dy = n_out;
         } else {
-            TC_TRY(tc_colsum(TC_BF16, dy, n_out, nullptr, 0, dbias, M, n_out, stream));
+            TC_TRY(tc_colsum(TC_BF16, dy, ld_dy, nullptr, 0, dbias, M, n_out, stream));
         }
-        TC_TRY(tc_gemm_tn(dyb, n_out, x, n_in, w.slabs, n_in, M, n_out, n_in, splits, stream));
+        TC_TRY(tc_gemm_tn(dyb, ld_dy, x, ld_x, w.slabs, n_in, M, n_out, n_in, splits, stream));
     } else {
-        TC_TRY(tc_transpose_cast(in_dt, dt, dy, n_out, w.tr_a, Mp, dy_rowmajor, n_out, dbias, M, n_out, stream));
-        TC_TRY(tc_transpose_cast(dt, dt, x, n_in, w.tr_b, Mp, nullptr, 0, nullptr, M, n_in, stream));
+        TC_TRY(tc_transpose_cast(in_dt, dt, dy, ld_dy, w.tr_a, Mp, dy_rowmajor, n_out, dbias, M, n_out, stream));
+        TC_TRY(tc_transpose_cast(dt, dt, x, ld_x, w.tr_b, Mp, nullptr, 0, nullptr, M, n_in, stream));
         TC_TRY(tc_gemm_train(dt, TC_EPI_PLAIN_F32, w.tr_a, Mp, w.tr_b, nullptr, nullptr, w.slabs, nullptr, n_in,
                              n_out, n_in, Mp, splits, stream));
     }
@@ -218,9 +225,9 @@ extern "C" int tc_encoder_forward_train(const tc_encoder_desc *d, const int32_t 
         TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, sv.ao, E, lw.w_o, lw.b_o, sv.x_in, sv.x_mid, E, M, E, E, 0.f, nullptr,
                        nullptr, 0, 0, stream));
         TC_TRY(ln(sv.x_mid, lw.ln2_g, lw.ln2_b, sv.h2));
-        TC_TRY(tc_gemm_train(dt, TC_EPI_BIAS_GELU_SAVE, sv.h2, E, lw.w_fc1, lw.b_fc1, nullptr, sv.mid, sv.u, F, M, F,
+        TC_TRY(tc_gemm_train(dt, TC_EPI_BIAS_GELU_SAVE, sv.h2, E, lw.w_fc1, lw.b_fc1, nullptr, sv.mid, sv.u, w.ld_f, M, F,
                              E, 1, stream));
-        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, sv.mid, F, lw.w_fc2, lw.b_fc2, sv.x_mid, x_next, E, M, E, F, 0.f,
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, sv.mid, w.ld_f, lw.w_fc2, lw.b_fc2, sv.x_mid, x_next, E, M, E, F, 0.f,
                        nullptr, nullptr, 0, 0, stream));
     }
     TC_TRY(ln(w.x, d->lnf_g, d->lnf_b, w.hf));
@@ -284,7 +291,7 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
                                   d->ln_eps, stream));
         TC_TRY(tc_layernorm_bwd(dt, h.g_act, E, h.ln_g, d_ln, w.t1, 0, h.d_ln_g, h.d_ln_b, M, E, d->ln_eps, stream));
         TC_TRY(tc_dgelu(dt, w.t1, h.u, w.dyb, (long)M * E, stream));
-        TC_TRY(linear_wgrad(d, w, dt, w.dyb, nullptr, w.hf, M, E, E, g->w_heads + h.wofs, g->b_heads + (h.wofs ? E : 0),
+        TC_TRY(linear_wgrad(d, w, dt, w.dyb, E, nullptr, w.hf, E, M, E, E, g->w_heads + h.wofs, g->b_heads + (h.wofs ? E : 0),
                             stream));
         TC_TRY(transpose_weight(d, w, w_heads + h.wofs * esz, E, E, stream));
         if (!have_dhf)
@@ -307,24 +314,25 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
                        lg.w_fc1 && lg.b_fc1 && lg.w_fc2 && lg.b_fc2,
                    "tc_encoder_backward: layer %d has a null gradient pointer", l);
         // ---- feed-forward block: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) ----
-        TC_TRY(linear_wgrad(d, w, TC_F32, dx, w.dyb, sv.mid, M, E, F, lg.w_fc2, lg.b_fc2, stream));
+        TC_TRY(linear_wgrad(d, w, TC_F32, dx, E, w.dyb, sv.mid, w.ld_f, M, E, F, lg.w_fc2, lg.b_fc2, stream));
         TC_TRY(transpose_weight(d, w, lw.w_fc2, E, F, stream));
-        TC_TRY(tc_gemm_train(dt, TC_EPI_DGELU, w.dyb, E, w.wt, nullptr, sv.u, w.wide, nullptr, F, M, F, E, 1, stream));
-        TC_TRY(linear_wgrad(d, w, dt, w.wide, nullptr, sv.h2, M, F, E, lg.w_fc1, lg.b_fc1, stream));
+        TC_TRY(tc_gemm_train(dt, TC_EPI_DGELU, w.dyb, E, w.wt, nullptr, sv.u, w.wide, nullptr, w.ld_f, M, F, E, 1,
+                             stream));
+        TC_TRY(linear_wgrad(d, w, dt, w.wide, w.ld_f, nullptr, sv.h2, E, M, F, E, lg.w_fc1, lg.b_fc1, stream));
         TC_TRY(transpose_weight(d, w, lw.w_fc1, F, E, stream));
-        TC_TRY(tc_gemm_train(dt, TC_EPI_PLAIN_F32, w.wide, F, w.wt, nullptr, nullptr, w.t0, nullptr, E, M, E, F, 1,
+        TC_TRY(tc_gemm_train(dt, TC_EPI_PLAIN_F32, w.wide, w.ld_f, w.wt, nullptr, nullptr, w.t0, nullptr, E, M, E, F, 1,
                              stream));
         TC_TRY(tc_layernorm_bwd(TC_F32, sv.x_mid, E, lw.ln2_g, w.t0, dx, 1, lg.ln2_g, lg.ln2_b, M, E, d->ln_eps,
                                 stream));
         // ---- attention block: x_mid = x_in + out_proj(attn(rope(qkv(LN1(x_in))))) ----
-        TC_TRY(linear_wgrad(d, w, TC_F32, dx, w.dyb, sv.ao, M, E, E, lg.w_o, lg.b_o, stream));
+        TC_TRY(linear_wgrad(d, w, TC_F32, dx, E, w.dyb, sv.ao, E, M, E, E, lg.w_o, lg.b_o, stream));
         TC_TRY(transpose_weight(d, w, lw.w_o, E, E, stream));
         void *d_ao = w.tr_b;      // free between weight-gradient products
         TC_TRY(tc_gemm(dt, TC_EPI_BIAS, w.dyb, E, w.wt, nullptr, nullptr, d_ao, E, M, E, E, 0.f, nullptr, nullptr, 0, 0,
                        stream));
         TC_TRY(tc_attn_bwd(dt, sv.qkv, 3 * E, w.words, sv.ao, d_ao, sv.lse, w.delta, w.wide, 3 * E, lw.rope_cos,
                            lw.rope_sin, 0.125f, B, T, d->H, 64, stream));
-        TC_TRY(linear_wgrad(d, w, dt, w.wide, nullptr, sv.h1, M, 3 * E, E, lg.w_qkv, lg.b_qkv, stream));
+        TC_TRY(linear_wgrad(d, w, dt, w.wide, 3 * E, nullptr, sv.h1, E, M, 3 * E, E, lg.w_qkv, lg.b_qkv, stream));
         TC_TRY(transpose_weight(d, w, lw.w_qkv, 3 * E, E, stream));
         TC_TRY(tc_gemm_train(dt, TC_EPI_PLAIN_F32, w.wide, 3 * E, w.wt, nullptr, nullptr, w.t0, nullptr, E, M, E, 3 * E,
                              1, stream));

@@ -50,7 +50,6 @@ struct GemmParams {
     float q_scale;
     int gm;          // large-tile kernel: row panels per ordering group (1 = n-fastest)
     int gn;          // large-tile kernel: column panels per ordering group (tiles_n = no grouping)
-    int stagger;     // alternating kernel: start delay per workgroup class, in shader clocks
 #ifdef TC_GEMM_STAMPS
     unsigned long long *stamps;   // per workgroup: wait, issue, math, epilogue cycles (wave 0)
     int nostore;                  // experiment: the large-tile epilogue skips its final stores
@@ -397,10 +396,11 @@ __device__ __forceinline__ void init_acc256(const GemmParams &p, f32x4 (&acc)[4]
 
 // Epilogue of one wave tile.  Phase 1: arithmetic in place (its table loads are not queued
 // behind any store); phase 2: all stores.
-template <typename T, int EPI, int LAY = 0, int MI0 = 0, int MI1 = 8, int NI0 = 0, int NI1 = 4>
+template <typename T, int EPI, int LAY = 0, int MI0 = 0, int MI1 = 8, int NI0 = 0, int NI1 = 4, bool LDSROPE = false>
 __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4][8], int tm, int tn, int mrow0,
                                             int ncol0, int wm, int wn, int frow, int fgrp,
-                                            const char *bias_lds = nullptr) {
+                                            const char *bias_lds = nullptr, const char *rope_lds = nullptr,
+                                            const char *step_lds = nullptr) {
     using namespace k256;
     constexpr bool kPreloadResidual = EPI == TC_EPI_BIAS_RESIDUAL && sizeof(T) == 2;
     const int section = EPI == TC_EPI_QKV_ROPE ? (tn * BN) / p.E : 0;
@@ -488,7 +488,42 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
                 acc[ni][mi] = v;
             }
     } else if constexpr (EPI == TC_EPI_QKV_ROPE) {
-        if (section < 2) {
+        if constexpr (LDSROPE) {
+            static_assert(LAY == 2, "the LDS rotary path is written for the interleaved column order");
+            // cos/sin of this wave's first 16 rows and the lane's 4 rotary pairs were staged into
+            // LDS (cos: 1 KiB, lane-linear; sin: the next 1 KiB); step_lds holds rows 16 and 80 of
+            // both tables (cos16, sin16, cos80, sin80: 32 pairs each).  Row blocks follow by angle
+            // addition: +16 rows, and +80 rows from block 3 to block 4.
+            if (section < 2) {
+                const float qs = section == 0 ? p.q_scale : 1.0f;
+                const int L = fgrp * 16 + frow;
+                f32x4 c = *reinterpret_cast<const f32x4 *>(rope_lds + L * 16);
+                f32x4 sn = *reinterpret_cast<const f32x4 *>(rope_lds + 1024 + L * 16);
+                const int p0 = (((ncol0 - tn * BN) & 63) >> 1) * 4;      // byte offset of the lane's first pair
+                const f32x4 c16 = *reinterpret_cast<const f32x4 *>(step_lds + p0);
+                const f32x4 s16 = *reinterpret_cast<const f32x4 *>(step_lds + 128 + p0);
+#pragma unroll
+                for (int mi = MI0; mi < MI1; ++mi) {
+#pragma unroll
+                    for (int ni = NI0; ni < NI1; ++ni) {
+                        const int e = (ni & 1) * 2;
+                        const f32x4 v = acc[ni][mi] * qs;
+                        acc[ni][mi] = f32x4{v[0] * c[e] - v[1] * sn[e], v[1] * c[e] + v[0] * sn[e],
+                                            v[2] * c[e + 1] - v[3] * sn[e + 1], v[3] * c[e + 1] + v[2] * sn[e + 1]};
+                    }
+                    if (mi + 1 < MI1) {
+                        f32x4 cs = c16, ss = s16;
+                        if (mi == 3) {
+                            cs = *reinterpret_cast<const f32x4 *>(step_lds + 256 + p0);
+                            ss = *reinterpret_cast<const f32x4 *>(step_lds + 384 + p0);
+                        }
+                        const f32x4 cn = c * cs - sn * ss;
+                        sn = sn * cs + c * ss;
+                        c = cn;
+                    }
+                }
+            }
+        } else if (section < 2) {
             const float qs = section == 0 ? p.q_scale : 1.0f;
             const int half = p.head_dim >> 1;
             // this lane's 4 columns of n-tile ni are rotary pairs pi(ni) + fgrp*2 + {0,1}
@@ -823,12 +858,15 @@ constexpr int BM = 256, BN = 256;
 constexpr int HALF_BYTES = 128 * 128;           // one half-tile (16 KiB)
 constexpr int DBUF_BYTES = 4 * HALF_BYTES;      // A0 A1 B0 B1
 constexpr int SLOT_A0 = 0, SLOT_A1 = HALF_BYTES, SLOT_B0 = 2 * HALF_BYTES, SLOT_B1 = 3 * HALF_BYTES;
-constexpr int BIAS_BYTES = 2 * 8 * 1024;        // per wave and tile parity: 256 floats
-constexpr int LDS_BYTES = 2 * DBUF_BYTES + BIAS_BYTES;   // 144 KiB
+// per wave, after the operand buffers: the tile's 256 bias values (1 KiB), the rotary cos and sin
+// of the wave's first 16 rows x the lane's 4 pairs (2 KiB), rows 16 and 80 of both tables (512 B)
+constexpr int BIAS_OFF = 2 * DBUF_BYTES, ROPE_OFF = BIAS_OFF + 8 * 1024, STEP_OFF = ROPE_OFF + 8 * 2048;
+constexpr int LDS_BYTES = STEP_OFF + 8 * 512;   // 156 KiB
 }  // namespace k256x
 
 constexpr bool piecewise_epilogue(int epi) {
-    return epi == TC_EPI_BIAS || epi == TC_EPI_BIAS_GELU || epi == TC_EPI_BIAS_GELU_SAVE || epi == TC_EPI_PLAIN_F32;
+    return epi == TC_EPI_BIAS || epi == TC_EPI_BIAS_GELU || epi == TC_EPI_BIAS_GELU_SAVE ||
+           epi == TC_EPI_PLAIN_F32 || epi == TC_EPI_QKV_ROPE;
 }
 
 #define TC_XBAR()                                  \
@@ -912,13 +950,24 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         glds16(base + (src[0] + koff), dst);
         glds16(base + (src[1] + koff), dst + 1024);
     };
-    // this wave's private copy of a tile's 256 bias values, two tiles deep
+    // This wave's private copies of what a tile's epilogue reads: staged in the tile's second
+    // k-tile (before that k-tile's A1, so the phase-3 wait covers them), read after its last.
     const bool lds_bias = kPiece && p.bias != nullptr;
-    auto bias_slot = [&](int local) -> char * { return smem + 2 * DBUF_BYTES + ((local & 1) * 8 + wid) * 1024; };
-    auto stage_bias = [&](int local) {
+    char *const bias_slot = smem + BIAS_OFF + wid * 1024;
+    char *const rope_slot = smem + ROPE_OFF + wid * 2048;
+    char *const step_slot = smem + STEP_OFF + wid * 512;
+    auto stage_epilogue_inputs = [&](int local) {
         int tm, tn;
         tile_coords(local, tm, tn);
-        glds16(reinterpret_cast<const char *>(p.bias + tn * BN + lane * 4), bias_slot(local));
+        if (lds_bias) glds16(reinterpret_cast<const char *>(p.bias + tn * BN + lane * 4), bias_slot);
+        if constexpr (EPI == TC_EPI_QKV_ROPE) {
+            if ((tn * BN) / p.E < 2) {
+                // lane (fgrp, frow): row tile_pos0 + wr*64 + frow, pairs ((wc*32 + fgrp*8) % 64) / 2 .. + 3
+                const long e = (long)((tm * BM) % p.T + wr * 64 + frow) * 32 + (((wc * 32 + fgrp * 8) & 63) >> 1);
+                glds16(reinterpret_cast<const char *>(p.rope_cos + e), rope_slot);
+                glds16(reinterpret_cast<const char *>(p.rope_sin + e), rope_slot + 1024);
+            }
+        }
     };
 
     int a_off[2], b_off[2];
@@ -935,15 +984,16 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         }
     }
 
-    if (p.stagger > 0) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        const unsigned long long span = (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned)p.stagger;
-        while (__builtin_amdgcn_s_memtime() - t0 < span) __builtin_amdgcn_s_sleep(32);
-    }
     // ---- prologue: all of k-tile 0, and B0 A0 B1 of k-tile 1 (the host guarantees nk >= 2) ----
     set_c1(0);
     set_c2(0);
-    if (lds_bias) stage_bias(0);
+    if constexpr (EPI == TC_EPI_QKV_ROPE) {
+        // rows 16 and 80 of the tables: 4 x 128 bytes, lanes 0..31
+        if (lane < 32) {
+            const float *tab = (lane & 8) ? p.rope_sin : p.rope_cos;
+            glds16(reinterpret_cast<const char *>(tab + ((lane & 16) ? 80 : 16) * 32 + (lane & 7) * 4), step_slot);
+        }
+    }
     stage_half(SLOT_B0, p.W, b0_src, 0);
     stage_half(SLOT_A0, p.A, a0_src, 0);
     stage_half(SLOT_B1, p.W, b1_src, 0);
@@ -970,8 +1020,8 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         int tm, tn;
         tile_coords(local, tm, tn);
         const int mrow0 = tm * BM + wr * 64 + frow, ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);
-        epilogue256<T, EPI, kLay>(p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp,
-                               lds_bias ? bias_slot(local) : nullptr);
+        epilogue256<T, EPI, kLay, 0, 8, 0, 4, EPI == TC_EPI_QKV_ROPE>(
+            p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, lds_bias ? bias_slot : nullptr, rope_slot, step_slot);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -1037,7 +1087,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             // Order inside a phase: LDS-DMA issue, then (first k-tile only) the previous tile's
             // epilogue, while no operand fragment is live, then the LDS reads.
             // ---- phase 0 ----
-            if (lds_bias && kt == 1 && t + 1 < my_count) stage_bias(t + 1);
+            if (kPiece && kt == 1) stage_epilogue_inputs(t);
             if (c1_tile < my_count) {
                 stage_half(nxt + SLOT_A1, p.A, a1_src, (unsigned)c1_k * 128u);
                 if (++c1_k == p.nk) { c1_k = 0; if (++c1_tile < my_count) set_c1(c1_tile); }
@@ -1171,10 +1221,13 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
         p.stamps = g_stamps;
         { const char *e = getenv("TC_GEMM_NOSTORE"); p.nostore = e ? atoi(e) : 0; }
 #endif
-        { const char *e = getenv("TC_GEMM_STAGGER"); p.stagger = e ? atoi(e) * p.nk : 0; }
         static int alt = -1;            // TC_GEMM_ALT=0 selects the single-group schedule
         if (alt < 0) { const char *e = getenv("TC_GEMM_ALT"); alt = e ? atoi(e) != 0 : 1; }
-        if (alt) {
+        // the alternating kernel's rotary epilogue steps through a tile by angle addition: no
+        // sequence boundary inside a 256-row tile, head dimension 64
+        bool use_alt = alt != 0;
+        if (EPI == TC_EPI_QKV_ROPE && (p.T % 256 != 0 || p.head_dim != 64)) use_alt = false;
+        if (use_alt) {
             static bool attr_set_x = false;
             if (!attr_set_x) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256x_kernel<T, EPI>),
