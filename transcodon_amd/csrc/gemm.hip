@@ -146,6 +146,37 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
     return r;
 }
 
+// GELU through a table of Phi in LDS (bf16 results of the large-tile kernel).  The pre-activation is
+// rounded to bf16 first, as a bf16 linear layer followed by GELU does, so gelu(u) = u * Phi(u) is a
+// function of 16 bits: entry (sign << 11) | clamp(|bits| - 0x3980, 0, 2047) covers 2^-12 <= |u| < 16
+// exactly; below that Phi is 0.5 to 1e-4, above it 1 or 0.  Costs 13 VALU operations and two LDS
+// gathers per pair of values instead of four transcendentals and about 17 operations.
+constexpr int kPhiEntries = 4096;
+__device__ __forceinline__ float phi_entry(int e) {
+    const unsigned bits = (0x3980u + (e & 2047)) | ((unsigned)(e >> 11) << 15);
+    const float u = __builtin_bit_cast(float, bits << 16);
+    const float z = fabsf(u) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(t, 1.061405429f, -1.453152027f);
+    poly = fmaf(t, poly, 1.421413741f);
+    poly = fmaf(t, poly, -0.284496736f);
+    poly = fmaf(t, poly, 0.254829592f);
+    poly *= t;
+    const float half_erfc = 0.5f * poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    return u < 0.f ? half_erfc : 1.0f - half_erfc;
+}
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+__device__ __forceinline__ f32x2 gelu_table2(f32x2 x, const char *phi) {
+    const uint32_t w = tc_pack_bf16(x[0], x[1]);
+    const u16x2 mag = __builtin_bit_cast(u16x2, w & 0x7fff7fffu);
+    u16x2 idx = __builtin_elementwise_sub_sat(mag, u16x2{0x3980, 0x3980});
+    idx = __builtin_elementwise_min(idx, u16x2{2047, 2047});
+    const uint32_t i2 = __builtin_bit_cast(uint32_t, idx) | ((w >> 4) & 0x08000800u);
+    const float p0 = *reinterpret_cast<const float *>(phi + ((i2 << 2) & 0x3fffcu));
+    const float p1 = *reinterpret_cast<const float *>(phi + ((i2 >> 14) & 0x3fffcu));
+    return f32x2{tc_bf16_lo(w), tc_bf16_hi(w)} * f32x2{p0, p1};
+}
+
 // d/dx gelu(x) = Phi(x) + x phi(x); Phi from the same erfc as gelu_fast (bf16 path) or exact erf.
 template <bool FAST>
 __device__ __forceinline__ float gelu_grad(float x) {
@@ -396,11 +427,13 @@ __device__ __forceinline__ void init_acc256(const GemmParams &p, f32x4 (&acc)[4]
 
 // Epilogue of one wave tile.  Phase 1: arithmetic in place (its table loads are not queued
 // behind any store); phase 2: all stores.
-template <typename T, int EPI, int LAY = 0, int MI0 = 0, int MI1 = 8, int NI0 = 0, int NI1 = 4, bool LDSROPE = false>
+template <typename T, int EPI, int LAY = 0, int MI0 = 0, int MI1 = 8, int NI0 = 0, int NI1 = 4, bool LDSX = false>
 __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4][8], int tm, int tn, int mrow0,
                                             int ncol0, int wm, int wn, int frow, int fgrp,
                                             const char *bias_lds = nullptr, const char *rope_lds = nullptr,
                                             const char *step_lds = nullptr) {
+    // LDSX: rope_lds / step_lds hold the rotary slices (q/k/v epilogue), or rope_lds the Phi table
+    // (GELU epilogues)
     using namespace k256;
     constexpr bool kPreloadResidual = EPI == TC_EPI_BIAS_RESIDUAL && sizeof(T) == 2;
     const int section = EPI == TC_EPI_QKV_ROPE ? (tn * BN) / p.E : 0;
@@ -478,7 +511,10 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
 #pragma unroll
             for (int mi = MI0; mi < MI1; ++mi) {
                 f32x4 v = acc[ni][mi];
-                if constexpr (sizeof(T) == 2) {
+                if constexpr (LDSX) {
+                    const f32x2 lo = gelu_table2(f32x2{v[0], v[1]}, rope_lds), hi = gelu_table2(f32x2{v[2], v[3]}, rope_lds);
+                    v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                } else if constexpr (sizeof(T) == 2) {
                     const f32x2 lo = gelu_fast2(f32x2{v[0], v[1]}), hi = gelu_fast2(f32x2{v[2], v[3]});
                     v = f32x4{lo[0], lo[1], hi[0], hi[1]};
                 } else {
@@ -488,7 +524,7 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
                 acc[ni][mi] = v;
             }
     } else if constexpr (EPI == TC_EPI_QKV_ROPE) {
-        if constexpr (LDSROPE) {
+        if constexpr (LDSX) {
             static_assert(LAY == 2, "the LDS rotary path is written for the interleaved column order");
             // cos/sin of this wave's first 16 rows and the lane's 4 rotary pairs were staged into
             // LDS (cos: 1 KiB, lane-linear; sin: the next 1 KiB); step_lds holds rows 16 and 80 of
@@ -888,6 +924,8 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     // per lane and accumulator tile already
     constexpr int kLay = (EPI == TC_EPI_BIAS_RESIDUAL || EPI == TC_EPI_PLAIN_F32) ? 1 : 2;
     constexpr int kTileStores = EPI == TC_EPI_BIAS_GELU_SAVE ? 32 : (kLay == 2 ? 16 : 32);   // store instructions per wave
+    constexpr bool kGeluTable = EPI == TC_EPI_BIAS_GELU || EPI == TC_EPI_BIAS_GELU_SAVE;
+    static_assert(kPhiEntries * 4 <= STEP_OFF - ROPE_OFF, "the Phi table takes the place of the rotary slices");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1004,6 +1042,12 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     int c1_tile = 0, c1_k = 1;                   // next A1 to stage
     int c2_tile = 0, c2_k = 2;                   // next B0 A0 B1 to stage
     if (c2_k == p.nk) { c2_k = 0; c2_tile = 1; if (c2_tile < my_count) set_c2(c2_tile); }
+    if constexpr (kGeluTable) {
+#pragma unroll
+        for (int e = threadIdx.x; e < kPhiEntries; e += 512)
+            *reinterpret_cast<float *>(smem + ROPE_OFF + e * 4) = phi_entry(e);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     TC_XBAR();
     if (wr == 1) TC_XBAR();                       // row group 1 runs half a phase behind
@@ -1020,8 +1064,9 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         int tm, tn;
         tile_coords(local, tm, tn);
         const int mrow0 = tm * BM + wr * 64 + frow, ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);
-        epilogue256<T, EPI, kLay, 0, 8, 0, 4, EPI == TC_EPI_QKV_ROPE>(
-            p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, lds_bias ? bias_slot : nullptr, rope_slot, step_slot);
+        epilogue256<T, EPI, kLay, 0, 8, 0, 4, EPI == TC_EPI_QKV_ROPE || kGeluTable>(
+            p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, lds_bias ? bias_slot : nullptr,
+            kGeluTable ? smem + ROPE_OFF : rope_slot, step_slot);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
