@@ -166,15 +166,19 @@ __device__ __forceinline__ float phi_entry(int e) {
     return u < 0.f ? half_erfc : 1.0f - half_erfc;
 }
 typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
-__device__ __forceinline__ f32x2 gelu_table2(f32x2 x, const char *phi) {
-    const uint32_t w = tc_pack_bf16(x[0], x[1]);
+// table entries of the two bf16 values packed in w
+__device__ __forceinline__ f32x2 table_pair(uint32_t w, const char *tab) {
     const u16x2 mag = __builtin_bit_cast(u16x2, w & 0x7fff7fffu);
     u16x2 idx = __builtin_elementwise_sub_sat(mag, u16x2{0x3980, 0x3980});
     idx = __builtin_elementwise_min(idx, u16x2{2047, 2047});
     const uint32_t i2 = __builtin_bit_cast(uint32_t, idx) | ((w >> 4) & 0x08000800u);
-    const float p0 = *reinterpret_cast<const float *>(phi + ((i2 << 2) & 0x3fffcu));
-    const float p1 = *reinterpret_cast<const float *>(phi + ((i2 >> 14) & 0x3fffcu));
-    return f32x2{tc_bf16_lo(w), tc_bf16_hi(w)} * f32x2{p0, p1};
+    const float p0 = *reinterpret_cast<const float *>(tab + ((i2 << 2) & 0x3fffcu));
+    const float p1 = *reinterpret_cast<const float *>(tab + ((i2 >> 14) & 0x3fffcu));
+    return f32x2{p0, p1};
+}
+__device__ __forceinline__ f32x2 gelu_table2(f32x2 x, const char *phi) {
+    const uint32_t w = tc_pack_bf16(x[0], x[1]);
+    return f32x2{tc_bf16_lo(w), tc_bf16_hi(w)} * table_pair(w, phi);
 }
 
 // d/dx gelu(x) = Phi(x) + x phi(x); Phi from the same erfc as gelu_fast (bf16 path) or exact erf.
@@ -450,7 +454,8 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
     if constexpr (EPI == TC_EPI_BIAS_GELU_SAVE) {
         // pre-activation goes out first (kept for the backward pass), then GELU in place
         if constexpr (LAY == 2) {
-            const int L = fgrp * 16 + frow;                  // lane exchange as for the final stores
+            int L = fgrp * 16 + frow;
+        asm volatile("" : "+v"(L));                         // keeps the address arithmetic below out of the k-loop                  // lane exchange as for the final stores
             const int pull = (((L & 3) << 4) | (L >> 2)) << 2;
             const int mbase = tm * BM + wm * 64 + (L >> 2), nbase = tn * BN + wn * 32 + (L & 3) * 8;
 #pragma unroll
@@ -532,7 +537,8 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
             // addition: +16 rows, and +80 rows from block 3 to block 4.
             if (section < 2) {
                 const float qs = section == 0 ? p.q_scale : 1.0f;
-                const int L = fgrp * 16 + frow;
+                int L = fgrp * 16 + frow;
+        asm volatile("" : "+v"(L));                         // keeps the address arithmetic below out of the k-loop
                 f32x4 c = *reinterpret_cast<const f32x4 *>(rope_lds + L * 16);
                 f32x4 sn = *reinterpret_cast<const f32x4 *>(rope_lds + 1024 + L * 16);
                 const int p0 = (((ncol0 - tn * BN) & 63) >> 1) * 4;      // byte offset of the lane's first pair
@@ -629,7 +635,8 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
         // rows, so a store instruction would reach memory as 64 separate 16-byte writes.  The
         // 64 lanes exchange their 16 bytes first (lane 4 r + s takes the data of lane 16 s + r):
         // four neighbouring lanes then write 64 contiguous bytes of one row.
-        const int L = fgrp * 16 + frow;
+        int L = fgrp * 16 + frow;
+        asm volatile("" : "+v"(L));                         // keeps the address arithmetic below out of the k-loop
         const int pull = (((L & 3) << 4) | (L >> 2)) << 2;
         const int trow = L >> 2, tseg = L & 3;
         const int mbase = tm * BM + wm * 64, nbase = tn * BN + wn * 32 + tseg * (LAY == 2 ? 8 : 4);
@@ -1196,7 +1203,8 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         }
         if constexpr (!kPiece) {
             TC_STAMP(e0);
-            epilogue256<T, EPI, kLay>(p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp);
+            epilogue256<T, EPI, kLay, 0, 8, 0, 4, kGeluTable>(p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, nullptr,
+                                                              smem + ROPE_OFF);
 #ifdef TC_GEMM_STAMPS
             TC_STAMP(e1);
             c_epi += e1 - e0;
