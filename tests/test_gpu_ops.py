@@ -137,6 +137,65 @@ def test_gemm_large_tile_kernel(dtype, M, N, K):
         np.testing.assert_allclose(out.numpy(), ref.numpy(), **tol)
 
 
+@pytest.mark.parametrize("T", [256, 512, 1024])
+def test_gemm_large_tile_rope_aligned_sequences(T):
+    """Sequence length a multiple of the 256-row tile: the large-tile kernel takes the rotary
+    cos/sin of a tile's first rows through LDS and steps the other row blocks by angle addition
+    (rows 16 and 80 of the tables).  Checked against the table formula row by row; M is not a
+    multiple of the tile, so the last tile's masked rows are exercised as well."""
+    M, E, D = 128 * 256 + 200 * 256 + 77, 768, 64       # >= 256 tiles of 256 x 256
+    N, K = 3 * E, 768
+    a, w, b = _bf(_rand(M, K, seed=41)), _bf(_rand(N, K, seed=42, scale=0.05)), _rand(N, seed=43)
+    freqs = O.rope_freqs(D)
+    ang = torch.arange(T, dtype=torch.float32)[:, None] * freqs[None, :]
+    out = ops.gemm(a.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16), b.to(DEV), _lib.EPI_QKV_ROPE, q_scale=0.125,
+                   rope_cos=ang.cos().contiguous().to(DEV), rope_sin=ang.sin().contiguous().to(DEV), T=T,
+                   head_dim=D).float().cpu()
+    y = a @ w.t() + b
+    pos = torch.arange(M) % T
+    cs, sn = ang.cos()[pos].repeat_interleave(2, -1), ang.sin()[pos].repeat_interleave(2, -1)
+
+    def rot(t):
+        t = t.view(M, E // D, D)
+        rh = torch.stack((-t[..., 1::2], t[..., 0::2]), -1).reshape(t.shape)
+        return (t * cs[:, None, :] + rh * sn[:, None, :]).reshape(M, E)
+
+    ref = torch.cat([rot(y[:, :E] * 0.125), rot(y[:, E:2 * E]), y[:, 2 * E:]], 1)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("epi", ["bias", "gelu", "residual"])
+def test_gemm_large_tile_padded_rows(epi):
+    """Leading dimensions larger than the row length on both sides (the encoder pads its FFN
+    intermediate): results land in the right columns and the padding is left untouched."""
+    M, N, K, pad_a, pad_o = 66000, 1024, 512, 64, 72
+    a, w, b = _bf(_rand(M, K, seed=51)), _bf(_rand(N, K, seed=52, scale=0.05)), _rand(N, seed=53)
+    abuf = torch.full((M, K + pad_a), 7.0, dtype=torch.bfloat16, device=DEV)
+    abuf[:, :K] = a.to(DEV, torch.bfloat16)
+    y = a @ w.t() + b
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    wd, bd = w.to(DEV, torch.bfloat16), b.to(DEV)
+    if epi == "residual":
+        r = _rand(M, N + pad_o, seed=54)
+        obuf = r.to(DEV).clone()
+        rc = lib.tc_gemm(1, _lib.EPI_BIAS_RESIDUAL, abuf.data_ptr(), K + pad_a, wd.data_ptr(), bd.data_ptr(),
+                         obuf.data_ptr(), obuf.data_ptr(), N + pad_o, M, N, K, 1.0, None, None, 0, 0, s)
+        assert rc == 0
+        got = obuf.cpu()
+        np.testing.assert_allclose(got[:, :N].numpy(), (r[:, :N] + y).numpy(), rtol=1e-2, atol=3e-2)
+        assert torch.equal(got[:, N:], r[:, N:])
+    else:
+        obuf = torch.full((M, N + pad_o), -3.0, dtype=torch.bfloat16, device=DEV)
+        rc = lib.tc_gemm(1, _lib.EPI_BIAS if epi == "bias" else _lib.EPI_BIAS_GELU, abuf.data_ptr(), K + pad_a,
+                         wd.data_ptr(), bd.data_ptr(), None, obuf.data_ptr(), N + pad_o, M, N, K, 1.0, None, None, 0, 0, s)
+        assert rc == 0
+        got = obuf.float().cpu()
+        want = y if epi == "bias" else O.gelu(y)
+        np.testing.assert_allclose(got[:, :N].numpy(), want.numpy(), rtol=1e-2, atol=3e-2)
+        assert bool((got[:, N:] == -3.0).all())
+
+
 def test_gelu_fast_accuracy():
     """The bf16 GEMM epilogue uses a rational erf; check it against exact erf on a dense grid
     by running a GEMM with an identity weight (values land on the bf16 grid, error <= 1 bf16 ulp)."""
