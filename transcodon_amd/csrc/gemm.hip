@@ -1057,7 +1057,13 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     }
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     TC_XBAR();
-    if (wr == 1) TC_XBAR();                       // row group 1 runs half a phase behind
+    // Row group 1 runs half a phase behind.  With a deferred epilogue the offset lasts for the whole
+    // kernel; otherwise (epilogues that load from global memory and wait for it) the groups meet
+    // again after each tile's k-loop, run their epilogues and accumulator loads side by side, and
+    // part again at the next tile's first phase: the two memory waits overlap instead of adding up.
+    if constexpr (kPiece) {
+        if (wr == 1) TC_XBAR();
+    }
 
     f32x4 acc[4][8];                              // [ni][mi], D[n][m]
     if constexpr (kPiece) {
@@ -1095,7 +1101,10 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         tile_coords(t, tm, tn);
         const int mrow0 = tm * BM + wr * 64 + frow;           // + mi_off<1>(mi)
         const int ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);     // + ni_off<kLay>(ni)
-        if constexpr (!kPiece) init_acc256<T, EPI, kLay>(p, acc, mrow0, ncol0);
+        if constexpr (!kPiece) {
+            init_acc256<T, EPI, kLay>(p, acc, mrow0, ncol0);
+            if (wr == 1) TC_XBAR();
+        }
         const bool prev_full = kPiece && t > 0 && tile_full(t - 1);
 
         for (int kt = 0; kt < p.nk; ++kt, ++g) {
@@ -1202,6 +1211,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
 #endif
         }
         if constexpr (!kPiece) {
+            if (wr == 0) TC_XBAR();               // row group 1's last phase
             TC_STAMP(e0);
             epilogue256<T, EPI, kLay, 0, 8, 0, 4, kGeluTable>(p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, nullptr,
                                                               smem + ROPE_OFF);
@@ -1220,7 +1230,9 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     }
 #endif
     if constexpr (kPiece) finish_tile(my_count - 1);
-    if (wr == 0) TC_XBAR();                       // pairs with row group 1's last barrier
+    if constexpr (kPiece) {
+        if (wr == 0) TC_XBAR();                   // pairs with row group 1's last barrier
+    }
 }
 
 // =============================================================================================
