@@ -912,12 +912,16 @@ constexpr bool piecewise_epilogue(int epi) {
            epi == TC_EPI_PLAIN_F32 || epi == TC_EPI_QKV_ROPE;
 }
 
+#ifdef TC_ABL_NOBAR
+#define TC_XBAR() __builtin_amdgcn_sched_barrier(0)
+#else
 #define TC_XBAR()                                  \
     do {                                           \
         __builtin_amdgcn_sched_barrier(0);         \
         __builtin_amdgcn_s_barrier();              \
         __builtin_amdgcn_sched_barrier(0);         \
     } while (0)
+#endif
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
@@ -991,9 +995,11 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         }
     };
     auto stage_half = [&](int slot_off, const char *base, const unsigned (&src)[2], unsigned koff) {
+#ifndef TC_ABL_NODMA
         char *dst = smem + slot_off + wid * 2048;
         glds16(base + (src[0] + koff), dst);
         glds16(base + (src[1] + koff), dst + 1024);
+#endif
     };
     // This wave's private copies of what a tile's epilogue reads: staged in the tile's second
     // k-tile (before that k-tile's A1, so the phase-3 wait covers them), read after its last.
@@ -1132,17 +1138,29 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
+                    for (int ks = 0; ks < 2; ++ks) {
+#ifdef TC_ABL_NOREADS
+                        bq[nq][nb][ks] = f32x4{(float)kt, 1.f, 2.f, 3.f};
+                        asm volatile("" : "+v"(bq[nq][nb][ks]));
+#else
                         bq[nq][nb][ks] = *reinterpret_cast<const f32x4 *>(
                             sb + (nq ? SLOT_B1 : SLOT_B0) + b_off[ks] + nb * (kLay == 2 ? 512 : 2048));
+#endif
+                    }
             };
             auto read_a = [&](int mq) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
+                    for (int ks = 0; ks < 2; ++ks) {
+#ifdef TC_ABL_NOREADS
+                        af[i][ks] = f32x4{(float)kt, 1.f, 2.f, 3.f};
+                        asm volatile("" : "+v"(af[i][ks]));
+#else
                         af[i][ks] = *reinterpret_cast<const f32x4 *>(
                             sb + (mq ? SLOT_A1 : SLOT_A0) + a_off[ks] + i * 2048);
+#endif
+                    }
             };
 
             // Order inside a phase: LDS-DMA issue, then (first k-tile only) the previous tile's
