@@ -223,7 +223,10 @@ def test_attention_backward(dtype, B, T, H, lens):
 
 
 @pytest.mark.parametrize("M,I,J,splits", [(64, 128, 128, 1), (1000, 256, 384, 3), (33000, 768, 128, 16), (77, 128, 256, 4),
-                                          (33000, 768, 768, 28), (1000, 256, 512, 96), (4100, 768, 3072, 7)])   # 256-tile kernel
+                                          (33000, 768, 768, 28), (1000, 256, 512, 96), (4100, 768, 3072, 7),   # 256-tile kernel
+                                          # whole 64-token tiles, >= 2 per split: alternating-group 256-tile kernel
+                                          (4096, 768, 768, 28), (16384, 768, 3072, 7), (32768, 512, 512, 50),
+                                          (65536, 2304, 768, 10)])
 def test_gemm_tn_matches_matmul(M, I, J, splits):
     """dW = dY^T X straight from row-major operands (ragged last token tile, more splits than tiles)."""
     a, b = _bf(_rand(M, I, seed=41)), _bf(_rand(M, J, seed=42))

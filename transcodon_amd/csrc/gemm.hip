@@ -184,21 +184,23 @@ __device__ __forceinline__ f32x2 gelu_table2(f32x2 x, const char *phi) {
 // d/dx gelu(x) = Phi(x) + x phi(x); Phi from the same erfc as gelu_fast (bf16 path) or exact erf.
 template <bool FAST>
 __device__ __forceinline__ float gelu_grad(float x) {
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    float cdf;
     if constexpr (FAST) {
+        // exp(-x^2/2) serves both the density and the erfc approximation
         const float z = fabsf(x) * 0.70710678118654752440f;
         const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
         float poly = fmaf(t, 1.061405429f, -1.453152027f);
         poly = fmaf(t, poly, 1.421413741f);
         poly = fmaf(t, poly, -0.284496736f);
         poly = fmaf(t, poly, 0.254829592f);
-        const float h = 0.5f * poly * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-        cdf = x < 0.f ? h : 1.0f - h;
+        const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+        const float h = 0.5f * poly * t * e;
+        const float cdf = x < 0.f ? h : 1.0f - h;
+        return fmaf(x, 0.3989422804014327f * e, cdf);
     } else {
-        cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        return fmaf(x, pdf, cdf);
     }
-    return fmaf(x, pdf, cdf);
 }
 template <typename T>
 __device__ __forceinline__ float load_elem(const char *base, long idx) {

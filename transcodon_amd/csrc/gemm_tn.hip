@@ -9,6 +9,8 @@
 // grid.y splits the token range; split s writes its partial tile to out + s*slab (f32), to be
 // summed by tc_reduce_slabs (deterministic, no atomics).
 #include "common.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -256,6 +258,210 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TnParams p) {
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// 256 x 256 output tile, two wave groups in alternation (the schedule of gemm256x_kernel in
+// gemm.hip): the two waves of a SIMD (row group 0 / 1) run half a phase apart, one issuing its
+// 16 MFMAs of a phase (16x16x32: this shape sustains a higher clock than 32x32x16 on this chip)
+// while the other issues that phase's transposing LDS reads and LDS-DMA loads.
+// A k-tile (64 tokens) is four half-tiles of 64 rows x 256 bytes (the image of gemm_tn_kernel's
+// tile): A0 A1 = columns i0 .. +127, +128 .. +255 of dY, B0 B1 likewise of X.  A wave owns a
+// 64 (i) x 32 (j) block in each quarter of the output tile.  Phases of k-tile g (buffer g & 1):
+//   0: read B0, A0   stage A1 of k-tile g+1   math quarter (0,0)
+//   1: read B1       stage B0 of k-tile g+2   math (0,1)
+//   2: read A1       stage A0 of k-tile g+2   math (1,1)
+//   3: -             stage B1 of k-tile g+2   math (1,0); vmcnt(6) guarantees all of k-tile g+1
+// Needs M % 64 == 0 (no partial stage to zero-fill) and at least two k-tiles per token split.
+// ------------------------------------------------------------------------------------------
+namespace alt {
+constexpr int HALF_BYTES = KT * 256;            // 16 KiB
+constexpr int DBUF_BYTES = 4 * HALF_BYTES;
+constexpr int SLOT_A0 = 0, SLOT_A1 = HALF_BYTES, SLOT_B0 = 2 * HALF_BYTES, SLOT_B1 = 3 * HALF_BYTES;
+constexpr int LDS_BYTES = 2 * DBUF_BYTES;       // 128 KiB
+}  // namespace alt
+
+// two k-steps (32 tokens each) of one 16-column block: 4 transposing reads at at + SLOT + s * 8192 (+ 4096)
+template <int OFF>
+__device__ __forceinline__ void tn_read1(unsigned at, bf16x4 &v) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(at), "n"(OFF));
+}
+template <int SLOT>
+__device__ __forceinline__ void tn_read2(unsigned at, bf16x4 (&f)[2][2]) {
+    tn_read1<SLOT>(at, f[0][0]); tn_read1<SLOT + 4096>(at, f[0][1]);
+    tn_read1<SLOT + 8192>(at, f[1][0]); tn_read1<SLOT + 8192 + 4096>(at, f[1][1]);
+}
+// every LDS read of this wave has landed; the fragments are handed on through the statement so
+// that no use of them can be scheduled above it
+__device__ __forceinline__ void tn_wait(bf16x4 (&f)[2][2], bf16x4 (&g)[2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[1][0]),
+                   "+v"(g[1][1]));
+}
+__device__ __forceinline__ bf16x8 tn_join(bf16x4 l, bf16x4 h) {
+    return __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+#define TN_XBAR()                                  \
+    do {                                           \
+        __builtin_amdgcn_sched_barrier(0);         \
+        __builtin_amdgcn_s_barrier();              \
+        __builtin_amdgcn_sched_barrier(0);         \
+    } while (0)
+
+__global__ __launch_bounds__(512) void gemm_tn256x_kernel(const TnParams p) {
+    using namespace alt;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int tile = blockIdx.x;
+    const int i0 = (tile / p.tiles_j) * 256, j0 = (tile % p.tiles_j) * 256;
+    const int k_begin = (int)((long)p.nk * blockIdx.y / p.splits);
+    const int nkt = (int)((long)p.nk * (blockIdx.y + 1) / p.splits) - k_begin;      // >= 2 (host)
+
+    // staging: a half-tile is 16 pieces of 4 rows x 256 B; this wave moves pieces 2 wid, 2 wid + 1
+    const int srow = lane >> 4, schunk = lane & 15;
+    long a_src[2][2], b_src[2][2];               // [half][piece]: byte offset of this lane's 16 bytes in token row 0
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wid * 2 + i) * 4 + srow;
+        const long rc = (long)((schunk ^ swz(r)) << 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            a_src[h][i] = r * p.lda_bytes + (long)(i0 + h * 128) * 2 + rc;
+            b_src[h][i] = r * p.ldb_bytes + (long)(j0 + h * 128) * 2 + rc;
+        }
+    }
+    auto stage_half = [&](int slot_off, const char *base, long ld_bytes, const long (&src)[2], int kt) {
+        char *dst = smem + slot_off + wid * 2048;
+        const char *row0 = base + (long)(k_begin + kt) * KT * ld_bytes;
+        __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(row0 + src[0]), TC_LDS_PTR(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(row0 + src[1]), TC_LDS_PTR(dst + 1024), 16, 0, 0);
+    };
+
+    // Transposed-read offsets inside a half-tile (row pitch 256 B).  A 16-lane group g = lane >> 4
+    // addresses tokens 4g + q (q = (lane & 15) >> 2), bytes 8p .. 8p+7 (p = lane & 3) of a 16-column
+    // block and receives, per lane, the 4 tokens of column lane & 15; a fragment of the 16x16x32
+    // MFMA is that read plus the one 16 tokens further (its k order is the same for both operands);
+    // + 8192 per k-step of 32 tokens.  The swizzle depends on (token & 7) = 4 (g & 1) + q only.
+    const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3, c16 = lane & 15;
+    const int row_l = 4 * tg + tq, sw = swz(row_l);
+    int a_off[4], b_off[2];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+        a_off[blk] = row_l * 256 + (((wr * 8 + blk * 2 + (tp >> 1)) ^ sw) << 4) + 8 * (tp & 1);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+        b_off[blk] = row_l * 256 + (((wc * 4 + blk * 2 + (tp >> 1)) ^ sw) << 4) + 8 * (tp & 1);
+    // The transposing reads are written in assembly: through the builtin the compiler cannot tell
+    // them from the LDS-DMA writes in flight and puts vmcnt(0) in front of every group, which would
+    // drain the prefetch each phase.  The price: nothing waits for them automatically, so every
+    // fragment passes through wait_frags() (lgkmcnt(0)) before an MFMA reads it.
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char *)smem;
+    unsigned a_addr[4], b_addr[2];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) a_addr[blk] = lds0 + (unsigned)a_off[blk];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) b_addr[blk] = lds0 + (unsigned)b_off[blk];
+
+    // ---- prologue: all of k-tile 0, and B0 A0 B1 of k-tile 1 ----
+    stage_half(SLOT_B0, p.B, p.ldb_bytes, b_src[0], 0);
+    stage_half(SLOT_A0, p.A, p.lda_bytes, a_src[0], 0);
+    stage_half(SLOT_B1, p.B, p.ldb_bytes, b_src[1], 0);
+    stage_half(SLOT_A1, p.A, p.lda_bytes, a_src[1], 0);
+    stage_half(DBUF_BYTES + SLOT_B0, p.B, p.ldb_bytes, b_src[0], 1);
+    stage_half(DBUF_BYTES + SLOT_A0, p.A, p.lda_bytes, a_src[0], 1);
+    stage_half(DBUF_BYTES + SLOT_B1, p.B, p.ldb_bytes, b_src[1], 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    TN_XBAR();
+    if (wr == 1) TN_XBAR();                       // row group 1 runs half a phase behind
+
+    f32x4 acc[8][4];                              // [mq * 4 + i block][nq * 2 + j block], D[i][j]
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int g = 0; g < nkt; ++g) {
+        const int cur = (g & 1) * DBUF_BYTES, nxt = DBUF_BYTES - cur;
+        bf16x4 bq[2][2][2][2];                    // [nq][j block][k-step][lower / upper 16 tokens]
+        bf16x4 af[4][2][2];                       // [i block][k-step][lower / upper] of the current mq
+        auto read_b = [&](auto nq_c) {
+            constexpr int nq = decltype(nq_c)::value;
+            tn_read2<(nq ? SLOT_B1 : SLOT_B0)>(b_addr[0] + cur, bq[nq][0]);
+            tn_read2<(nq ? SLOT_B1 : SLOT_B0)>(b_addr[1] + cur, bq[nq][1]);
+        };
+        auto read_a = [&](auto mq_c, auto half_c) {          // i blocks 2 half, 2 half + 1
+            constexpr int mq = decltype(mq_c)::value, hf = decltype(half_c)::value;
+            tn_read2<(mq ? SLOT_A1 : SLOT_A0)>(a_addr[2 * hf] + cur, af[2 * hf]);
+            tn_read2<(mq ? SLOT_A1 : SLOT_A0)>(a_addr[2 * hf + 1] + cur, af[2 * hf + 1]);
+        };
+        auto math = [&](int mq, int nq) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int ib = 0; ib < 4; ++ib)
+                        acc[mq * 4 + ib][nq * 2 + jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            tn_join(af[ib][s][0], af[ib][s][1]), tn_join(bq[nq][jb][s][0], bq[nq][jb][s][1]),
+                            acc[mq * 4 + ib][nq * 2 + jb], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        // ---- phase 0 ----
+        if (g + 1 < nkt) stage_half(nxt + SLOT_A1, p.A, p.lda_bytes, a_src[1], g + 1);
+        read_b(I0{});
+        read_a(I0{}, I0{});
+        // the B0 reads (8 of the 16 issued; the counter holds 15): their slot is restaged in phase 1
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        read_a(I0{}, I1{});
+        TN_XBAR();
+        tn_wait(bq[0][0], bq[0][1]); tn_wait(af[0], af[1]); tn_wait(af[2], af[3]);
+        math(0, 0);
+        TN_XBAR();
+        // ---- phase 1 ----
+        const bool more = g + 2 < nkt;
+        if (more) stage_half(cur + SLOT_B0, p.B, p.ldb_bytes, b_src[0], g + 2);
+        read_b(I1{});
+        TN_XBAR();
+        tn_wait(bq[1][0], bq[1][1]);
+        math(0, 1);
+        TN_XBAR();
+        // ---- phase 2 ----
+        if (more) stage_half(cur + SLOT_A0, p.A, p.lda_bytes, a_src[0], g + 2);
+        read_a(I1{}, I0{});
+        read_a(I1{}, I1{});
+        TN_XBAR();
+        tn_wait(af[0], af[1]); tn_wait(af[2], af[3]);
+        math(1, 1);
+        TN_XBAR();
+        // ---- phase 3 ----
+        if (more) {
+            stage_half(cur + SLOT_B1, p.B, p.ldb_bytes, b_src[1], g + 2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        TN_XBAR();
+        math(1, 0);
+        TN_XBAR();
+    }
+    if (wr == 0) TN_XBAR();                       // pairs with row group 1's last barrier
+
+    float *out = p.out + (long)blockIdx.y * p.slab_elems;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = j0 + (b >> 1) * 128 + wc * 32 + (b & 1) * 16 + c16;
+            const int i = i0 + (a >> 2) * 128 + wr * 64 + (a & 3) * 16 + 4 * tg;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(long)(i + r) * p.ldo + j] = acc[a][b][r];
+        }
+}
+
 // column sums (and optional bf16 copy) of a row-major matrix: 8 columns per thread
 template <typename TI>
 __global__ __launch_bounds__(256) void colsum_kernel(const TI *__restrict__ x, long ld, uint16_t *__restrict__ copy,
@@ -332,6 +538,9 @@ extern "C" int tc_gemm_tn(const void *A, int lda, const void *B, int ldb, float 
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn256_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn256x_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, alt::LDS_BYTES);
         if (e != hipSuccess) {
             tc_set_error("tc_gemm_tn: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return TC_ELAUNCH;
@@ -344,7 +553,13 @@ extern "C" int tc_gemm_tn(const void *A, int lda, const void *B, int ldb, float 
     const long big_wgs = (long)(I / 256) * (J / 256) * splits;
     if (I % 256 == 0 && J % 256 == 0 && big_wgs >= 192) {
         p.tiles_j = J / 256;
-        hipLaunchKernelGGL(gemm_tn256_kernel, dim3((I / 256) * (J / 256), splits), dim3(512), big::LDS_BYTES, s, p);
+        static int alt_on = -1;                   // TC_TN_ALT=0 keeps the single-group kernel
+        if (alt_on < 0) { const char *e = getenv("TC_TN_ALT"); alt_on = e ? atoi(e) != 0 : 1; }
+        // the alternating kernel has no partial stage and wants two k-tiles in every token split
+        if (alt_on && M % KT == 0 && p.nk >= 2 * splits && (long)M * lda * 2 < (1L << 40))
+            hipLaunchKernelGGL(gemm_tn256x_kernel, dim3((I / 256) * (J / 256), splits), dim3(512), alt::LDS_BYTES, s, p);
+        else
+            hipLaunchKernelGGL(gemm_tn256_kernel, dim3((I / 256) * (J / 256), splits), dim3(512), big::LDS_BYTES, s, p);
     } else {
         hipLaunchKernelGGL(gemm_tn_kernel, dim3((I / 128) * (J / 128), splits), dim3(256), LDS_BYTES, s, p);
     }
