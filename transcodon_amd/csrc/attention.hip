@@ -42,6 +42,8 @@ constexpr int ATTN_LDS_BYTES = 2 * KV_STAGE_BYTES;   // the output staging reuse
 __device__ __forceinline__ int swz_k(int row) { return (row >> 1) & 7; }          // row reads
 __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }   // transposed reads
 
+constexpr int kMaxWords = 128;   // key tiles whose validity words are kept in LDS (T <= 8192)
+
 __device__ __forceinline__ uint64_t key_word(const AttnParams &p, int b, int kt) {
     if (p.words) return p.words[(long)b * p.nw + kt];
     const int rem = p.T - kt * 64;
@@ -60,9 +62,16 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
     const int q0 = qb * 128 + wid * 32;
     const long row_base = (long)b * p.T;
 
+    // The key-validity words of this batch row go to LDS once: a global load consumed inside the
+    // key loop would make the compiler wait for everything in flight, the K/V prefetch included.
+    __shared__ uint64_t s_words[kMaxWords];
+    for (int i = threadIdx.x; i < p.nw && i < kMaxWords; i += 256) s_words[i] = key_word(p, b, i);
+    __syncthreads();
+    auto tile_word = [&](int kt) { return s_words[kt]; };       // the host checks nw <= kMaxWords
+
     // number of key tiles up to the last one holding a valid key
     int nkt = p.nw;
-    while (nkt > 0 && key_word(p, b, nkt - 1) == 0ull) --nkt;
+    while (nkt > 0 && tile_word(nkt - 1) == 0ull) --nkt;
 
     // ---- Q fragments: B operand, lane (q, h2) holds Q[q][16 ks + 8 h2 .. +7] ----
     bf16x8 qf[4];
@@ -121,6 +130,19 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    // LDS byte address of this lane's V reads for d block db, key rows 4 h2 + tq of a stage: the
+    // key-block / k-step / upper-half terms are immediates of the read instruction
+    const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char *)smem;
+    const unsigned v_lane[2] = {lds_base + (unsigned)v_off(0, 4 * h2 + tq), lds_base + (unsigned)v_off(1, 4 * h2 + tq)};
+    auto v_read_pair = [&](unsigned at, int kb, int s, bf16x4 &lo, bf16x4 &hi) {
+        // rows + (32 kb + 16 s) and + 8 more: the swizzle of a row depends on bit 1 of it only
+        switch (kb * 2 + s) {
+            case 0: asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(lo), "=&v"(hi) : "v"(at)); break;
+            case 1: asm volatile("ds_read_b64_tr_b16 %0, %2 offset:2048\n\tds_read_b64_tr_b16 %1, %2 offset:3072" : "=&v"(lo), "=&v"(hi) : "v"(at)); break;
+            case 2: asm volatile("ds_read_b64_tr_b16 %0, %2 offset:4096\n\tds_read_b64_tr_b16 %1, %2 offset:5120" : "=&v"(lo), "=&v"(hi) : "v"(at)); break;
+            default: asm volatile("ds_read_b64_tr_b16 %0, %2 offset:6144\n\tds_read_b64_tr_b16 %1, %2 offset:7168" : "=&v"(lo), "=&v"(hi) : "v"(at)); break;
+        }
+    };
 
     if (nkt > 0) stage(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
@@ -128,6 +150,8 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
         __syncthreads();
         if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
         const char *sb = smem + (kt & 1) * KV_STAGE_BYTES;
+        const unsigned v_at[2] = {v_lane[0] + (unsigned)((kt & 1) * KV_STAGE_BYTES),
+                                  v_lane[1] + (unsigned)((kt & 1) * KV_STAGE_BYTES)};
 
         // S^T[key][query]
         f32x16 acc_s[2];
@@ -145,7 +169,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
         // mask + online softmax in base 2.  The running maximum is kept in scaled (log2) units, so
         // the scale folds into one fma per pair in front of the exponential; the padded-key select
         // runs only for tiles that contain a padded key (wave-uniform branch).
-        const uint64_t word = key_word(p, b, kt);
+        const uint64_t word = tile_word(kt);
         if (word != ~0ull) {
             const uint64_t wsh = word >> (4 * h2);
 #pragma unroll
@@ -196,18 +220,17 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
                 bf16x8 pf;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[j] = (__bf16)acc_s[kb][8 * s + j];
-                const int key0 = kb * 32 + 16 * s + 4 * h2 + tq;   // + 8 for elements 4..7
+                // The transposing reads are issued from assembly: through the builtin the compiler
+                // cannot tell them from the LDS-DMA writes of the next tile in flight and waits for
+                // that prefetch (vmcnt(0)) in the middle of every iteration.
+                bf16x4 lo[2], hi[2];
+                v_read_pair(v_at[0], kb, s, lo[0], hi[0]);
+                v_read_pair(v_at[1], kb, s, lo[1], hi[1]);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]));
 #pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4 *)(sb + v_off(db, key0)));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4 *)(sb + v_off(db, key0 + 8)));
-                    bf16x8 vf;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-                    acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc_o[db], 0, 0, 0);
-                }
+                for (int db = 0; db < 2; ++db)
+                    acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_shufflevector(lo[db], hi[db], 0, 1, 2, 3, 4, 5, 6, 7), pf, acc_o[db], 0, 0, 0);
             }
     }
 
@@ -406,6 +429,7 @@ static int attn_fwd_impl(int dtype, const void *qkv, int ldq, const uint64_t *ke
         p.nqb = (T + 127) / 128;
         const long grid = (long)p.nqb * H * B;
         TC_REQUIRE(grid < (1L << 31), "tc_attn_fwd: grid too large");
+        TC_REQUIRE(p.nw <= kMaxWords, "tc_attn_fwd: T=%d exceeds the bf16 kernel's %d keys", T, kMaxWords * 64);
         hipLaunchKernelGGL(attn_bf16_kernel, dim3((unsigned)grid), dim3(256), ATTN_LDS_BYTES, s, p);
     } else {
         p.nqb = (T + 63) / 64;
