@@ -43,6 +43,23 @@ struct BwdParams {
 __device__ __forceinline__ int swz_row(int row) { return (row >> 1) & 7; }         // row reads
 __device__ __forceinline__ int swz_tr(int row) { return ((row >> 1) & 1) << 2; }   // transposed reads
 
+constexpr int kMaxWords = 128;   // key tiles whose validity words the bf16 kernels keep in LDS (T <= 8192)
+
+// Two transposing reads, rows r and r + 8 of a 128-byte-pitch image (lo / hi half of a fragment),
+// issued from assembly: through the builtin the compiler cannot tell them from the LDS-DMA writes
+// of the next tile in flight and waits for that prefetch (vmcnt(0)) in the middle of the loop.
+// The caller waits (tr_wait) before an MFMA reads the result.
+template <int OFF>
+__device__ __forceinline__ void tr_read_pair(unsigned at, bf16x4 &lo, bf16x4 &hi) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(at), "n"(OFF), "n"(OFF + 1024));
+}
+__device__ __forceinline__ void tr_wait(bf16x4 &a, bf16x4 &b, bf16x4 &c, bf16x4 &d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ bf16x8 tr_join(bf16x4 l, bf16x4 h) { return __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7); }
+
 __device__ __forceinline__ uint64_t key_word(const BwdParams &p, int b, int kt) {
     const int rem = p.T - kt * 64;
     const uint64_t in_range = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
@@ -118,8 +135,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const BwdParams p
     const int q0 = qb * 128 + wid * 32;
     const long row_base = (long)b * p.T;
 
+    // the key-validity words of this batch row go to LDS once (a global load consumed inside the
+    // key loop would make the compiler wait for the K/V prefetch in the middle of an iteration)
+    __shared__ uint64_t s_words[kMaxWords];
+    for (int i = threadIdx.x; i < p.nw && i < kMaxWords; i += 256) s_words[i] = key_word(p, b, i);
+    __syncthreads();
     int nkt = p.nw;
-    while (nkt > 0 && key_word(p, b, nkt - 1) == 0ull) --nkt;
+    while (nkt > 0 && s_words[nkt - 1] == 0ull) --nkt;
 
     // Q and dO fragments (B operands) and the query's lse / delta
     bf16x8 qf[4], dof[4];
@@ -179,6 +201,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const BwdParams p
         return row * 128 + ((c ^ swz_tr(row)) << 4) + 8 * (tp & 1);
     };
 
+    // LDS byte address of this lane's transposed K reads for d block db, key rows 4 h2 + tq of a stage
+    const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char *)smem;
+    const unsigned tr_lane[2] = {lds_base + (unsigned)t_off(0, 4 * h2 + tq), lds_base + (unsigned)t_off(1, 4 * h2 + tq)};
+
     f32x16 acc_dq[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -191,6 +217,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const BwdParams p
         __syncthreads();
         if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
         const char *sb = smem + (kt & 1) * DQ_STAGE_BYTES;
+        const unsigned kt_at[2] = {tr_lane[0] + (unsigned)((kt & 1) * DQ_STAGE_BYTES),
+                                   tr_lane[1] + (unsigned)((kt & 1) * DQ_STAGE_BYTES)};
 
         f32x16 acc_s[2], acc_p[2];
 #pragma unroll
@@ -208,7 +236,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const BwdParams p
 
         // P = exp2(S log2e - lse log2e), dS = P (dP - delta): packed f32 arithmetic; padded keys get
         // S = -inf first (only in tiles that contain one: wave-uniform branch)
-        const uint64_t word = key_word(p, b, kt);
+        const uint64_t word = s_words[kt];
         if (word != ~0ull) {
             const uint64_t wsh = word >> (4 * h2);
 #pragma unroll
@@ -243,18 +271,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const BwdParams p
                 bf16x8 df;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) df[j] = (__bf16)acc_s[kb][8 * s + j];
-                const int key0 = kb * 32 + 16 * s + 4 * h2 + tq;
+                // rows + (32 kb + 16 s): immediates; the lane part (4 h2 + tq, swizzle) is in kt_at
+                bf16x4 lo[2], hi[2];
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4 *)(sb + TILE_BYTES + t_off(db, key0)));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4 *)(sb + TILE_BYTES + t_off(db, key0 + 8)));
-                    bf16x8 kf;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { kf[j] = lo[j]; kf[4 + j] = hi[j]; }
-                    acc_dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, df, acc_dq[db], 0, 0, 0);
+                    switch (kb * 2 + s) {
+                        case 0: tr_read_pair<TILE_BYTES>(kt_at[db], lo[db], hi[db]); break;
+                        case 1: tr_read_pair<TILE_BYTES + 2048>(kt_at[db], lo[db], hi[db]); break;
+                        case 2: tr_read_pair<TILE_BYTES + 4096>(kt_at[db], lo[db], hi[db]); break;
+                        default: tr_read_pair<TILE_BYTES + 6144>(kt_at[db], lo[db], hi[db]); break;
+                    }
                 }
+                tr_wait(lo[0], hi[0], lo[1], hi[1]);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    acc_dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(lo[db], hi[db]), df, acc_dq[db], 0, 0, 0);
             }
     }
 
@@ -368,6 +399,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const BwdParams 
         return row * 128 + ((c ^ swz_tr(row)) << 4) + 8 * (tp & 1);
     };
 
+    // LDS byte address of this lane's transposed reads for d block db, query rows 4 h2 + tq of an image
+    const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char *)smem;
+    const unsigned tr_lane[2] = {lds_base + (unsigned)t_off(0, 4 * h2 + tq), lds_base + (unsigned)t_off(1, 4 * h2 + tq)};
+
     f32x16 acc_dk[2], acc_dv[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -380,6 +415,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const BwdParams 
         __syncthreads();
         if (qt + 1 < nqt) stage((qt + 1) & 1, qt + 1);
         const char *sb = smem + (qt & 1) * DKV_STAGE_BYTES;
+        const unsigned tr_at[2] = {tr_lane[0] + (unsigned)((qt & 1) * DKV_STAGE_BYTES),
+                                   tr_lane[1] + (unsigned)((qt & 1) * DKV_STAGE_BYTES)};
         const float *lse_s = reinterpret_cast<const float *>(sb + 4 * TILE_BYTES);
         const float *dlt_s = lse_s + 64;
         const bool ragged = qt * 64 + 64 > p.T;
@@ -443,23 +480,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const BwdParams 
                     pf[j] = (__bf16)acc_s[8 * s + j];
                     df[j] = (__bf16)acc_p[8 * s + j];
                 }
-                const int row0 = qb * 32 + 16 * s + 4 * h2 + tq;
+                // query rows + (32 qb + 16 s): immediates; the lane part (4 h2 + tq, swizzle) is in tr_at
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const int o_lo = t_off(db, row0), o_hi = t_off(db, row0 + 8);
-                    const bf16x4 dlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4 *)(sb + 3 * TILE_BYTES + o_lo));
-                    const bf16x4 dhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4 *)(sb + 3 * TILE_BYTES + o_hi));
-                    const bf16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4 *)(sb + TILE_BYTES + o_lo));
-                    const bf16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4 *)(sb + TILE_BYTES + o_hi));
-                    bf16x8 dt, qt_;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { dt[j] = dlo[j]; dt[4 + j] = dhi[j]; qt_[j] = qlo[j]; qt_[4 + j] = qhi[j]; }
-                    acc_dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt, pf, acc_dv[db], 0, 0, 0);
-                    acc_dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_, df, acc_dk[db], 0, 0, 0);
+                    bf16x4 dlo, dhi, qlo, qhi;
+                    switch (qb * 2 + s) {
+                        case 0:
+                            tr_read_pair<3 * TILE_BYTES>(tr_at[db], dlo, dhi);
+                            tr_read_pair<TILE_BYTES>(tr_at[db], qlo, qhi);
+                            break;
+                        case 1:
+                            tr_read_pair<3 * TILE_BYTES + 2048>(tr_at[db], dlo, dhi);
+                            tr_read_pair<TILE_BYTES + 2048>(tr_at[db], qlo, qhi);
+                            break;
+                        case 2:
+                            tr_read_pair<3 * TILE_BYTES + 4096>(tr_at[db], dlo, dhi);
+                            tr_read_pair<TILE_BYTES + 4096>(tr_at[db], qlo, qhi);
+                            break;
+                        default:
+                            tr_read_pair<3 * TILE_BYTES + 6144>(tr_at[db], dlo, dhi);
+                            tr_read_pair<TILE_BYTES + 6144>(tr_at[db], qlo, qhi);
+                            break;
+                    }
+                    tr_wait(dlo, dhi, qlo, qhi);
+                    acc_dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(dlo, dhi), pf, acc_dv[db], 0, 0, 0);
+                    acc_dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(qlo, qhi), df, acc_dk[db], 0, 0, 0);
                 }
             }
         }
@@ -711,6 +756,7 @@ extern "C" int tc_attn_bwd(int dtype, const void *qkv, int ldq, const uint64_t *
         p.nblk = (T + 127) / 128;
         const long grid = (long)p.nblk * H * B;
         TC_REQUIRE(grid < (1L << 31), "tc_attn_bwd: grid too large");
+        TC_REQUIRE(p.nw <= kMaxWords, "tc_attn_bwd: T=%d exceeds the bf16 kernels' %d keys", T, kMaxWords * 64);
         hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3((unsigned)grid), dim3(256), DQ_LDS_BYTES, s, p);
         TC_CHECK_LAUNCH("tc_attn_bwd(dq)");
         hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3((unsigned)grid), dim3(256), DKV_LDS_BYTES, s, p);
