@@ -15,7 +15,7 @@ from collections import defaultdict
 
 def short(name):
     """Kernel family of a (possibly mangled) kernel name; None for kernels that are not ours."""
-    m = re.search(r"(gemm128_kernel|gemm256x_kernel|gemm256_kernel|gemm_tn256_kernel|gemm_tn_kernel|mlm_mask_kernel|attn_bwd_dq_bf16_kernel|attn_bwd_dkv_bf16_kernel|"
+    m = re.search(r"(gemm128_kernel|gemm256x_kernel|gemm256_kernel|gemm_tn256x_kernel|gemm_tn256_kernel|gemm_tn_kernel|mlm_mask_kernel|attn_bwd_dq_bf16_kernel|attn_bwd_dkv_bf16_kernel|"
                   r"attn_bf16_kernel|attn_f32_kernel|layernorm_bwd_kernel|layernorm_kernel|head_bwd_kernel|"
                   r"head_kernel|embed_bwd_kernel|embed_kernel|decode_kernel|key_mask_kernel|colsum_kernel|"
                   r"reduce_slabs_kernel|rope_bwd_kernel|adamw_kernel|delta_kernel|transpose_kernel)", name)
