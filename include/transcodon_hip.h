@@ -93,6 +93,11 @@ int tc_layernorm_fwd(const float *x, const float *gamma, const float *beta, floa
  *       (multihead_attention.py:265,358-360; rotary-embedding-torch 0.8.6).
  * Requirements: N % 128 == 0, K % 64 == 0 (bf16) or K % 32 == 0 (f32), lda >= K, 16-byte
  * aligned pointers.
+ * bf16 problems with N % 256 == 0 and at least one 256 x 256 tile per compute unit take the
+ * large-tile kernels; there GELU is applied to the pre-activation rounded to bf16 (what a bf16
+ * linear layer followed by GELU computes), and the q/k/v epilogue, when T % 256 == 0, also reads
+ * rows 16 and 80 of the rotary tables.  A result whose rows are 6144 bytes apart stores slowly on
+ * this memory system: prefer ldo = N + 64 for N = 3072 in bf16.
  */
 int tc_gemm(int dtype, int epilogue, const void *A, int lda, const void *W, const float *bias,
             const float *residual, void *out, int ldo, int M, int N, int K, float q_scale,
@@ -127,7 +132,8 @@ int tc_key_mask_words(const uint8_t *pad_flags, uint64_t *words, int B, int T, v
  * transcodon/multihead_attention.py:362-398 (bmm, masked_fill -inf, fp32 softmax, bmm,
  * head concat).  qkv [B*T, ldq] holds q at column 0, k at column E, v at column 2E
  * (E = H*D); out [B*T, E]; element type `dtype`.  key_words from tc_key_mask_words, or
- * NULL when no key is padded.  D must be 64.
+ * NULL when no key is padded.  D must be 64; the bf16 kernels take T <= 8192 (forward and
+ * backward) and reject longer sequences.
  */
 int tc_attn_fwd(int dtype, const void *qkv, int ldq, const uint64_t *key_words, void *out, int B,
                 int T, int H, int D, void *stream);
