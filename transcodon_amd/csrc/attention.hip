@@ -154,15 +154,15 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
                                   v_lane[1] + (unsigned)((kt & 1) * KV_STAGE_BYTES)};
 
         // S^T[key][query]
+        // the first MFMA of each chain takes the constant 0 as its C operand: no accumulator clearing
         f32x16 acc_s[2];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc_s[kb][r] = 0.f;
-#pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(sb + k_off[kb][ks]);
-                acc_s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc_s[kb], 0, 0, 0);
+                acc_s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : acc_s[kb], 0, 0, 0);
             }
         }
 
