@@ -953,15 +953,18 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     const int first = cls < r ? cls * (q + 1) : r * (q + 1) + (cls - r) * q;
     const int count = q + (cls < r ? 1 : 0);
     const int my_count = count > j ? (count - j + per_class - 1) / per_class : 0;
-    auto tile_coords = [&](int local, int &tm, int &tn) {
-        const int tile = first + j + local * per_class;
-        const int per_group = p.gm * p.tiles_n;
-        const int grp = tile / per_group, loc = tile - grp * per_group;
-        const int rows_here = min(p.gm, p.tiles_m - grp * p.gm);
-        tn = loc / rows_here;
-        tm = grp * p.gm + (loc - tn * rows_here);
-    };
     if (my_count == 0) return;
+    // Tile order: column panel fastest.  A workgroup's tiles are per_class apart, so (row panel,
+    // column panel) advances by a fixed step with one carry: no division after this point (each
+    // one is a 100-clock dependent chain, and six cursors a tile would pay it).
+    const int step_m = per_class / p.tiles_n, step_n = per_class - step_m * p.tiles_n;
+    const int tile0 = first + j;
+    const int tm0 = tile0 / p.tiles_n, tn0 = tile0 - tm0 * p.tiles_n;
+    auto advance = [&](int &tm, int &tn) {
+        tn += step_n;
+        tm += step_m;
+        if (tn >= p.tiles_n) { tn -= p.tiles_n; ++tm; }
+    };
 
     // ---- staging: a half-tile is 16 pieces of 8 rows x 128 B; this wave moves pieces 2 wid, 2 wid + 1
     // The 16-byte chunk c of row r sits at chunk position c ^ key(r) of its LDS row.  A rows:
@@ -981,14 +984,10 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         const int chunk = kLay == 2 ? (lane & 7) ^ ((srow & 3) | (i << 2)) : schunk;
         return (unsigned)(tn * BN + h * 128 + (wid * 2 + i) * 8 + srow) * (unsigned)p.ldw_bytes + chunk * 16;
     };
-    auto set_c1 = [&](int local) {
-        int tm, tn;
-        tile_coords(local, tm, tn);
-        a1_src[0] = a_src_of(tm, 1, 0); a1_src[1] = a_src_of(tm, 1, 1);
-    };
-    auto set_c2 = [&](int local) {
-        int tm, tn;
-        tile_coords(local, tm, tn);
+    int c1m = tm0, c1n = tn0, c2m = tm0, c2n = tn0;      // tiles of the two staging cursors
+    auto set_c1 = [&]() { a1_src[0] = a_src_of(c1m, 1, 0); a1_src[1] = a_src_of(c1m, 1, 1); };
+    auto set_c2 = [&]() {
+        const int tm = c2m, tn = c2n;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             b0_src[i] = b_src_of(tn, 0, i);
@@ -1009,9 +1008,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     char *const bias_slot = smem + BIAS_OFF + wid * 1024;
     char *const rope_slot = smem + ROPE_OFF + wid * 2048;
     char *const step_slot = smem + STEP_OFF + wid * 512;
-    auto stage_epilogue_inputs = [&](int local) {
-        int tm, tn;
-        tile_coords(local, tm, tn);
+    auto stage_epilogue_inputs = [&](int tm, int tn) {
         if (lds_bias) glds16(reinterpret_cast<const char *>(p.bias + tn * BN + lane * 4), bias_slot);
         if constexpr (EPI == TC_EPI_QKV_ROPE) {
             if ((tn * BN) / p.E < 2) {
@@ -1038,8 +1035,8 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     }
 
     // ---- prologue: all of k-tile 0, and B0 A0 B1 of k-tile 1 (the host guarantees nk >= 2) ----
-    set_c1(0);
-    set_c2(0);
+    set_c1();
+    set_c2();
     if constexpr (EPI == TC_EPI_QKV_ROPE) {
         // rows 16 and 80 of the tables: 4 x 128 bytes, lanes 0..31
         if (lane < 32) {
@@ -1056,7 +1053,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     stage_half(DBUF_BYTES + SLOT_B1, p.W, b1_src, 128);
     int c1_tile = 0, c1_k = 1;                   // next A1 to stage
     int c2_tile = 0, c2_k = 2;                   // next B0 A0 B1 to stage
-    if (c2_k == p.nk) { c2_k = 0; c2_tile = 1; if (c2_tile < my_count) set_c2(c2_tile); }
+    if (c2_k == p.nk) { c2_k = 0; c2_tile = 1; if (c2_tile < my_count) { advance(c2m, c2n); set_c2(); } }
     if constexpr (kGeluTable) {
 #pragma unroll
         for (int e = threadIdx.x; e < kPhiEntries; e += 512)
@@ -1081,9 +1078,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // epilogue of tile `local` (bias from this wave's LDS copy), accumulators back to zero
-    auto finish_tile = [&](int local) {
-        int tm, tn;
-        tile_coords(local, tm, tn);
+    auto finish_tile = [&](int tm, int tn) {
         const int mrow0 = tm * BM + wr * 64 + frow, ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);
         epilogue256<T, EPI, kLay, 0, 8, 0, 4, EPI == TC_EPI_QKV_ROPE || kGeluTable>(
             p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, lds_bias ? bias_slot : nullptr,
@@ -1093,27 +1088,21 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    auto tile_full = [&](int local) {
-        int tm, tn;
-        tile_coords(local, tm, tn);
-        return tm * BM + BM <= p.M;
-    };
 
 #ifdef TC_GEMM_STAMPS
     unsigned long long c_kt[24] = {}, c_epi = 0;
     TC_STAMP(k_begin);
 #endif
     int g = 0;
+    int tm = tm0, tn = tn0, ptm = tm0, ptn = tn0;          // this tile and the one before it
     for (int t = 0; t < my_count; ++t) {
-        int tm, tn;
-        tile_coords(t, tm, tn);
         const int mrow0 = tm * BM + wr * 64 + frow;           // + mi_off<1>(mi)
         const int ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);     // + ni_off<kLay>(ni)
         if constexpr (!kPiece) {
             init_acc256<T, EPI, kLay>(p, acc, mrow0, ncol0);
             if (wr == 1) TC_XBAR();
         }
-        const bool prev_full = kPiece && t > 0 && tile_full(t - 1);
+        const bool prev_full = kPiece && t > 0 && ptm * BM + BM <= p.M;
 
         for (int kt = 0; kt < p.nk; ++kt, ++g) {
             const int cur = (g & 1) * DBUF_BYTES, nxt = DBUF_BYTES - cur;
@@ -1168,15 +1157,15 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             // Order inside a phase: LDS-DMA issue, then (first k-tile only) the previous tile's
             // epilogue, while no operand fragment is live, then the LDS reads.
             // ---- phase 0 ----
-            if (kPiece && kt == 1) stage_epilogue_inputs(t);
+            if (kPiece && kt == 1) stage_epilogue_inputs(tm, tn);
             if (c1_tile < my_count) {
                 stage_half(nxt + SLOT_A1, p.A, a1_src, (unsigned)c1_k * 128u);
-                if (++c1_k == p.nk) { c1_k = 0; if (++c1_tile < my_count) set_c1(c1_tile); }
+                if (++c1_k == p.nk) { c1_k = 0; if (++c1_tile < my_count) { advance(c1m, c1n); set_c1(); } }
             }
             if constexpr (kPiece) {
                 if (after) {
                     TC_STAMP(e0);
-                    finish_tile(t - 1);
+                    finish_tile(ptm, ptn);
                     __builtin_amdgcn_sched_barrier(0);
 #ifdef TC_GEMM_STAMPS
                     TC_STAMP(e1);
@@ -1211,7 +1200,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             // was masked, so that every store instruction was issued; the counter holds 63).
             if (more) {
                 stage_half(cur + SLOT_B1, p.W, b1_src, koff2);
-                if (++c2_k == p.nk) { c2_k = 0; if (++c2_tile < my_count) set_c2(c2_tile); }
+                if (++c2_k == p.nk) { c2_k = 0; if (++c2_tile < my_count) { advance(c2m, c2n); set_c2(); } }
                 if (after && prev_full) {
                     if constexpr (kTileStores == 32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
@@ -1240,6 +1229,9 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             c_epi += e1 - e0;
 #endif
         }
+        ptm = tm;
+        ptn = tn;
+        advance(tm, tn);
     }
 #ifdef TC_GEMM_STAMPS
     if (p.stamps && (threadIdx.x == 0 || threadIdx.x == 256)) {
@@ -1249,7 +1241,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         o[24] = c_epi; o[25] = k_end - k_begin; o[26] = my_count;
     }
 #endif
-    if constexpr (kPiece) finish_tile(my_count - 1);
+    if constexpr (kPiece) finish_tile(ptm, ptn);
     if constexpr (kPiece) {
         if (wr == 0) TC_XBAR();                   // pairs with row group 1's last barrier
     }
