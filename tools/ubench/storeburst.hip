@@ -48,8 +48,8 @@ __global__ __launch_bounds__(512) void k(char* out, long ld_bytes, int tiles_n, 
 }
 
 template <int PATTERN>
-void run(const char* name, char* out, long ld_bytes, int M, int N, int gap, unsigned long long* cyc) {
-    const int tiles_n = N / 256, ntiles = (M / 256) * tiles_n, grid = 256, tiles = ntiles / grid;
+void run(const char* name, char* out, long ld_bytes, int M, int N, int gap, unsigned long long* cyc, int grid = 256) {
+    const int tiles_n = N / 256, tiles = (M / 256) * tiles_n / 256, ntiles = tiles * grid;   // same tiles per workgroup
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k<PATTERN>, dim3(grid), dim3(512), 0, 0, out, ld_bytes, tiles_n, tiles, gap, cyc);
@@ -58,7 +58,7 @@ void run(const char* name, char* out, long ld_bytes, int M, int N, int gap, unsi
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / 5, bytes = (double)ntiles * 256 * 256 * 4;
-    printf("%-34s N=%d gap=%6d: %8.1f us  %6.2f TB/s (store-only time %8.1f us)\n", name, N, gap, us, bytes / us / 1e6,
+    printf("%-34s grid=%3d N=%d gap=%6d: %8.1f us  %6.2f TB/s (store-only time %8.1f us)\n", name, grid, N, gap, us, bytes / us / 1e6,
            us - (double)tiles * gap / 2300.0);
 }
 
@@ -74,5 +74,7 @@ int main() {
             run<2>("16 lanes x 16 B per row, 4 rows", out, (long)N * 4, M, N, gap, cyc);
         }
     }
+    // fewer workgroups, same work each: does one CU's burst drain faster when the others are idle?
+    for (int grid : {256, 128, 64, 32, 8}) run<0>("4 lanes x 16 B per row, 16 rows", out, 3072L * 4, M, 3072, 0, cyc, grid);
     return 0;
 }
