@@ -24,23 +24,30 @@ mid = torch.randn(M, F, device=dev, generator=g).bfloat16()
 res = torch.randn(M, E, device=dev, generator=g)
 ang = torch.arange(T, dtype=torch.float32)[:, None] * (1.0 / 10000 ** (torch.arange(0, 64, 2).float() / 64))[None]
 cos, sin = ang.cos().to(dev).contiguous(), ang.sin().to(dev).contiguous()
-stamps = torch.zeros(256 * 2 * 32, dtype=torch.int64, device=dev)
+stamps = torch.zeros(256 * 2 * 32 + 256 * 2 * 26, dtype=torch.int64, device=dev)
 lib.tc_debug_set_stamp_buffer(stamps.data_ptr())
-for name, a, N, K, epi in (("fc1", x, F, E, 1), ("qkv", x, 3 * E, E, 3), ("fc2", mid, E, F, 2)):
+for name, a, N, K, epi in (("bias", x, F, E, 0), ("fc1", x, F, E, 1), ("qkv", x, 3 * E, E, 3), ("out", x, E, E, 2)):
     w = (torch.randn(N, K, device=dev, generator=g) * 0.03).bfloat16()
     b = torch.randn(N, device=dev, generator=g) * 0.1
-    out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == 2 else torch.bfloat16)
+    ldo = N + 64 if N == F else N      # rows of 6144 bytes store slowly: pad them
+    out = torch.empty(M, ldo, device=dev, dtype=torch.float32 if epi == 2 else torch.bfloat16)
     s = torch.cuda.current_stream().cuda_stream
     for it in range(3):
         stamps.zero_()
         rc = lib.tc_gemm(1, epi, a.data_ptr(), K, w.data_ptr(), b.data_ptr(), res.data_ptr() if epi == 2 else None,
-                         out.data_ptr(), N, M, N, K, 0.125, cos.data_ptr(), sin.data_ptr(), T, 64, s)
+                         out.data_ptr(), ldo, M, N, K, 0.125, cos.data_ptr(), sin.data_ptr(), T, 64, s)
         assert rc == 0
     torch.cuda.synchronize()
-    st = stamps.view(256, 2, 32).double().cpu()
+    st = stamps[:256 * 2 * 32].view(256, 2, 32).double().cpu()
+    ph = stamps[256 * 2 * 32:].view(256, 2, 2, 13).double().cpu()
     for grp in (0, 1):
         m = st[:, grp].mean(0)
         tiles = float(m[26])
         per = [round(float(v) / tiles) for v in m[:24] if v > 0]
         print(f"{name} group {grp}: tiles/WG {tiles:.1f} total {m[25]:.0f} per tile {m[25] / tiles:.0f}  epilogue/tile {m[24] / tiles:.0f}  "
               f"k-tile by position {per}", flush=True)
+        if float(ph.sum()) > 0:          # library built with -DTC_GEMM_PHASES: a tile's first and last k-tile
+            for c, cname in enumerate(("first", "last")):
+                v = (ph[:, grp, c].mean(0) / tiles).tolist()
+                print(f"    {cname:5s} k-tile: issue+epilogue {v[0]:.0f} | reads {v[1]:.0f} | bar {v[2]:.0f} | mfma+bar {v[3]:.0f} || "
+                      f"p1: {v[4]:.0f} {v[5]:.0f} {v[6]:.0f} | p2: {v[7]:.0f} {v[8]:.0f} {v[9]:.0f} | p3: {v[10]:.0f} {v[11]:.0f} {v[12]:.0f}", flush=True)

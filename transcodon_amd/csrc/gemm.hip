@@ -1093,6 +1093,24 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     unsigned long long c_kt[24] = {}, c_epi = 0;
     TC_STAMP(k_begin);
 #endif
+#ifdef TC_GEMM_PHASES
+    // Hand-over profile: only a tile's first and last k-tile carry stamps (13 points each); slots
+    // [first / last][interval] accumulate shader clocks between consecutive points.
+    unsigned c_ph[2][13] = {};
+    unsigned long long ph_t = 0;
+#define TC_PH(i)                                                                              \
+    do {                                                                                      \
+        if (kt == 0 || kt == p.nk - 1) {                                                      \
+            const unsigned long long now__ = __builtin_amdgcn_s_memtime();                    \
+            c_ph[kt == 0 ? 0 : 1][i] += (unsigned)(now__ - ph_t);                             \
+            ph_t = now__;                                                                     \
+        }                                                                                     \
+    } while (0)
+#define TC_PH_START() do { if (kt == 0 || kt == p.nk - 1) ph_t = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TC_PH(i)
+#define TC_PH_START()
+#endif
     int g = 0;
     int tm = tm0, tn = tn0, ptm = tm0, ptn = tn0;          // this tile and the one before it
     for (int t = 0; t < my_count; ++t) {
@@ -1157,6 +1175,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             // Order inside a phase: LDS-DMA issue, then (first k-tile only) the previous tile's
             // epilogue, while no operand fragment is live, then the LDS reads.
             // ---- phase 0 ----
+            TC_PH_START();
             if (kPiece && kt == 1) stage_epilogue_inputs(tm, tn);
             if (c1_tile < my_count) {
                 stage_half(nxt + SLOT_A1, p.A, a1_src, (unsigned)c1_k * 128u);
@@ -1171,29 +1190,40 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
                     TC_STAMP(e1);
                     c_epi += e1 - e0;
 #endif
+                    if (wr == 1) TC_XBAR();        // the two groups ran this epilogue side by side: part again
                 }
             }
+            TC_PH(0);                              // DMA issue + previous tile's epilogue
             read_b(0);
             __builtin_amdgcn_sched_barrier(0);
             read_a(0);
             asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            TC_PH(1);                              // reads issued
             TC_XBAR();
+            TC_PH(2);                              // wait at barrier 1
             math(0, 0);
             TC_XBAR();
+            TC_PH(3);                              // MFMA + barrier 2
             // ---- phase 1 ----
             const bool more = c2_tile < my_count;
             const unsigned koff2 = (unsigned)c2_k * 128u;
             if (more) stage_half(cur + SLOT_B0, p.W, b0_src, koff2);
             read_b(1);
+            TC_PH(4);
             TC_XBAR();
+            TC_PH(5);
             math(0, 1);
             TC_XBAR();
+            TC_PH(6);
             // ---- phase 2 ----
             if (more) stage_half(cur + SLOT_A0, p.A, a0_src, koff2);
             read_a(1);
+            TC_PH(7);
             TC_XBAR();
+            TC_PH(8);
             math(1, 1);
             TC_XBAR();
+            TC_PH(9);
             // ---- phase 3 ----
             // The wait leaves in flight what was issued after this k-tile's A1: three half-tiles,
             // plus, in a tile's first k-tile, the previous tile's stores (when none of its rows
@@ -1210,9 +1240,12 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            TC_PH(10);                             // DMA issue + vmcnt wait
             TC_XBAR();
+            TC_PH(11);
             math(1, 0);
             TC_XBAR();
+            TC_PH(12);
 #ifdef TC_GEMM_STAMPS
             TC_STAMP(s1);
 #pragma unroll
@@ -1229,6 +1262,12 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             c_epi += e1 - e0;
 #endif
         }
+        // After a tile's last phase row group 0 waits for row group 1, so that both run the
+        // deferred epilogue at the same time (each hides the other's LDS and exchange latency)
+        // instead of one after the other; group 1 falls half a phase behind again right after it.
+        if constexpr (kPiece) {
+            if (wr == 0) TC_XBAR();
+        }
         ptm = tm;
         ptn = tn;
         advance(tm, tn);
@@ -1239,12 +1278,14 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         unsigned long long *o = p.stamps + (blockIdx.x * 2 + (threadIdx.x >> 8)) * 32;
         for (int i = 0; i < 24; ++i) o[i] = c_kt[i];
         o[24] = c_epi; o[25] = k_end - k_begin; o[26] = my_count;
+#ifdef TC_GEMM_PHASES
+        unsigned long long *o2 = p.stamps + 256 * 2 * 32 + (blockIdx.x * 2 + (threadIdx.x >> 8)) * 26;
+        for (int c = 0; c < 2; ++c)
+            for (int i = 0; i < 13; ++i) o2[c * 13 + i] = c_ph[c][i];
+#endif
     }
 #endif
     if constexpr (kPiece) finish_tile(ptm, ptn);
-    if constexpr (kPiece) {
-        if (wr == 0) TC_XBAR();                   // pairs with row group 1's last barrier
-    }
 }
 
 // =============================================================================================
