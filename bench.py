@@ -157,7 +157,7 @@ def bench_train(args, world, rank, dev, dist_on):
                                    "positions selected (80/10/10) on the device each step, AdamW lr 2e-4 wd 0.1, gradient mean over ranks",
                        "seqs_per_gpu": B, "seq_len": T, "parallelism": f"data-parallel x{world}",
                        "first_loss": round(float(losses[0]), 4), "last_loss": round(float(losses[-1]), 4)},
-            "roofline": {"bound": "mfma", "kernel": "gemm kernels (all GEMM launches of the step)",
+            "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel / gemm_tn256x_kernel (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
                          "traffic": pmc_traffic("r01_pmc_traffic_train.json"),
@@ -301,7 +301,7 @@ def main():
                                    "forward + LM/structure heads + greedy codon decode",
                        "seqs_per_gpu": B, "seq_len": T, "codons_per_s": round(tokens_total / elapsed / 3, 1),
                        "weights": "random init N(0,0.02), 89.8M params", "parallelism": f"batch-sharded x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16> (all GEMM launches of the step)",
+            "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel<bf16, EPI> (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
                          "traffic": pmc_traffic("r01_pmc_traffic_infer.json"),
