@@ -288,7 +288,7 @@ def _attn_ref(qkv, B, T, H, pad):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("B,T,H,lens", [(2, 131, 2, None), (3, 256, 3, [256, 130, 1]), (2, 70, 1, [70, 64]),
-                                        (1, 515, 2, None)])
+                                        (1, 515, 2, None), (2, 300, 2, [300, 257])])
 def test_attention_forward(dtype, B, T, H, lens):
     E = H * 64
     qkv = _rand(B * T, 3 * E, seed=21)

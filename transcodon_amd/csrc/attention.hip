@@ -1,8 +1,10 @@
 // Fused multi-head self-attention forward for head_dim 64 (gfx950).
 //
-// bf16 kernel: a 256-thread workgroup (4 waves) owns 128 query rows of one (sequence,
+// bf16 kernel: a 512-thread workgroup (8 waves) owns 256 query rows of one (sequence,
 // head); each wave owns 32 of them.  K/V tiles of 64 keys are staged global -> LDS with
-// direct loads, double buffered.  Per tile and wave:
+// direct loads, double buffered (one 8-row piece of K and one of V per wave and tile: the
+// issue of a direct-to-LDS load costs the wave about 60 cycles, so a tile shared by 8 waves
+// is cheaper than one shared by 4).  Per tile and wave:
 //   S^T = K . Q^T   (mfma_f32_32x32x16_bf16, A = K rows from LDS, B = Q kept in registers)
 // leaves the query on the lane and 32 keys in registers, so the online softmax is
 // lane-local plus one exchange with lane ^ 32;
@@ -37,7 +39,22 @@ constexpr int KV_TILE_BYTES = 64 * 128;            // 64 keys x 64 bf16
 constexpr int KV_STAGE_BYTES = 2 * KV_TILE_BYTES;  // K + V
 constexpr int OST_LD = 144;                        // bytes per staged output row (128 + pad)
 constexpr int OST_WAVE_BYTES = 32 * OST_LD;
-constexpr int ATTN_LDS_BYTES = 2 * KV_STAGE_BYTES;   // the output staging reuses the K/V stages after the loop
+#ifndef TC_ATTN_STAGES
+#define TC_ATTN_STAGES 2
+#endif
+#ifndef TC_ATTN_WAVES
+#define TC_ATTN_WAVES 8
+#endif
+constexpr int kWaves = TC_ATTN_WAVES;              // waves per workgroup, 32 queries each (4 or 8)
+constexpr int kPieces = 8 / kWaves;                // 8-row pieces of K (and of V) a wave stages per tile
+constexpr int kStages = TC_ATTN_STAGES;            // K/V ring depth: tiles in flight = kStages - 1
+#ifdef TC_ABL_LDS
+constexpr int ATTN_LDS_BYTES = TC_ABL_LDS;         // occupancy ablation
+#else
+constexpr int ATTN_LDS_BYTES = kStages * KV_STAGE_BYTES > kWaves * OST_WAVE_BYTES ? kStages * KV_STAGE_BYTES
+                                                                                  : kWaves * OST_WAVE_BYTES;
+#endif
+//   // the output staging reuses the K/V stages after the loop
 
 __device__ __forceinline__ int swz_k(int row) { return (row >> 1) & 7; }          // row reads
 __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }   // transposed reads
@@ -50,7 +67,7 @@ __device__ __forceinline__ uint64_t key_word(const AttnParams &p, int b, int kt)
     return rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
 }
 
-__global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
+__global__ __launch_bounds__(64 * kWaves) void attn_bf16_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -59,13 +76,14 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
     const int bh = id / p.nqb;
     const int h = bh % p.H, b = bh / p.H;
     const int ql = lane & 31, h2 = lane >> 5;
-    const int q0 = qb * 128 + wid * 32;
+    const int q0 = qb * (32 * kWaves) + wid * 32;
+    const bool q_live = q0 < p.T;                  // wave-uniform
     const long row_base = (long)b * p.T;
 
     // The key-validity words of this batch row go to LDS once: a global load consumed inside the
     // key loop would make the compiler wait for everything in flight, the K/V prefetch included.
     __shared__ uint64_t s_words[kMaxWords];
-    for (int i = threadIdx.x; i < p.nw && i < kMaxWords; i += 256) s_words[i] = key_word(p, b, i);
+    for (int i = threadIdx.x; i < p.nw && i < kMaxWords; i += 64 * kWaves) s_words[i] = key_word(p, b, i);
     __syncthreads();
     auto tile_word = [&](int kt) { return s_words[kt]; };       // the host checks nw <= kMaxWords
 
@@ -83,22 +101,22 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(src + ks * 32);
     }
 
-    // ---- staging: per tile and wave 2 pieces of K and 2 of V (8 rows x 128 B each) ----
+    // ---- staging: per tile and wave kPieces pieces of K and of V (8 rows x 128 B each) ----
     const int srow = lane >> 3;
     long k_src[2], v_src[2];      // byte offsets without the key-tile term
     int s_row[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (wid * 2 + i) * 8 + srow;
+    for (int i = 0; i < kPieces; ++i) {
+        const int r = (wid * kPieces + i) * 8 + srow;
         s_row[i] = r;
         k_src[i] = (long)(p.E + h * 64) * 2 + (((lane & 7) ^ swz_k(r)) << 4);
         v_src[i] = (long)(2 * p.E + h * 64) * 2 + (((lane & 7) ^ swz_v(r)) << 4);
     }
     auto stage = [&](int buf, int kt) {
-        char *kb = smem + buf * KV_STAGE_BYTES + wid * 2 * 1024;
+        char *kb = smem + buf * KV_STAGE_BYTES + wid * kPieces * 1024;
         char *vb = kb + KV_TILE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < kPieces; ++i) {
             int key = kt * 64 + s_row[i];
             key = key < p.T ? key : p.T - 1;
             const char *rowp = p.qkv + (row_base + key) * p.ldq_bytes;
@@ -145,13 +163,27 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
     };
 
     if (nkt > 0) stage(0, 0);
+    if (kStages == 3 && nkt > 1) stage(1, 1);
+    int buf = 0, buf_next = kStages - 1;           // ring slots of tile kt and of the tile staged at kt
     for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the 4 pieces of the younger tile in flight (3-deep ring) may stay outstanding
+        if (kStages == 3 && kt + 1 < nkt) {
+            if (kPieces == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef TC_ABL_NOBAR
         __syncthreads();
-        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
-        const char *sb = smem + (kt & 1) * KV_STAGE_BYTES;
-        const unsigned v_at[2] = {v_lane[0] + (unsigned)((kt & 1) * KV_STAGE_BYTES),
-                                  v_lane[1] + (unsigned)((kt & 1) * KV_STAGE_BYTES)};
+#endif
+#ifndef TC_ABL_NOSTAGE
+        if (kt + kStages - 1 < nkt) stage(buf_next, kt + kStages - 1);
+#endif
+        const char *sb = smem + buf * KV_STAGE_BYTES;
+        const unsigned v_at[2] = {v_lane[0] + (unsigned)(buf * KV_STAGE_BYTES),
+                                  v_lane[1] + (unsigned)(buf * KV_STAGE_BYTES)};
+        buf_next = buf;
+        buf = (buf + 1 == kStages) ? 0 : buf + 1;
+        if (!q_live) continue;                     // a wave without queries only stages and synchronises
 
         // S^T[key][query]
         // the first MFMA of each chain takes the constant 0 as its C operand: no accumulator clearing
@@ -182,11 +214,15 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
                 }
             }
         }
-        float tmax = -INFINITY;
+#ifndef TC_ABL_NOSOFTMAX
+        // two chains of three-input maxima (v_max3_f32): 18 instructions instead of 25
+        float tm0 = fmaxf(acc_s[0][0], acc_s[0][1]), tm1 = fmaxf(acc_s[1][0], acc_s[1][1]);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(acc_s[kb][r], acc_s[kb][r + 1]));
+        for (int r = 2; r < 16; r += 2) {
+            tm0 = fmaxf(fmaxf(tm0, acc_s[0][r]), acc_s[0][r + 1]);
+            tm1 = fmaxf(fmaxf(tm1, acc_s[1][r]), acc_s[1][r + 1]);
+        }
+        float tmax = fmaxf(tm0, tm1);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * kLog2e;
         const float m_new = fmaxf(m_run, tmax);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
@@ -198,7 +234,11 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const f32x2 t = f32x2{acc_s[kb][r], acc_s[kb][r + 1]} * scale2 + neg_m2;
+#ifdef TC_ABL_NOEXP
+                const f32x2 e = t;
+#else
                 const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+#endif
                 acc_s[kb][r] = e[0];
                 acc_s[kb][r + 1] = e[1];
                 lsum2 += e;
@@ -212,6 +252,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
                 for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
         }
 
+#endif
         // O^T[d][query] += V^T . P^T ; P fragment of k-step (kb, s) = registers 8s..8s+7
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -223,6 +264,10 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
                 // The transposing reads are issued from assembly: through the builtin the compiler
                 // cannot tell them from the LDS-DMA writes of the next tile in flight and waits for
                 // that prefetch (vmcnt(0)) in the middle of every iteration.
+#ifdef TC_ABL_NOPV
+                acc_o[0][8 * s] += (float)pf[0] + (float)pf[2] + (float)pf[4] + (float)pf[6];
+                continue;
+#endif
                 bf16x4 lo[2], hi[2];
                 v_read_pair(v_at[0], kb, s, lo[0], hi[0]);
                 v_read_pair(v_at[1], kb, s, lo[1], hi[1]);
@@ -426,11 +471,11 @@ static int attn_fwd_impl(int dtype, const void *qkv, int ldq, const uint64_t *ke
             }
             attr_set = true;
         }
-        p.nqb = (T + 127) / 128;
+        p.nqb = (T + 32 * kWaves - 1) / (32 * kWaves);
         const long grid = (long)p.nqb * H * B;
         TC_REQUIRE(grid < (1L << 31), "tc_attn_fwd: grid too large");
         TC_REQUIRE(p.nw <= kMaxWords, "tc_attn_fwd: T=%d exceeds the bf16 kernel's %d keys", T, kMaxWords * 64);
-        hipLaunchKernelGGL(attn_bf16_kernel, dim3((unsigned)grid), dim3(256), ATTN_LDS_BYTES, s, p);
+        hipLaunchKernelGGL(attn_bf16_kernel, dim3((unsigned)grid), dim3(64 * kWaves), ATTN_LDS_BYTES, s, p);
     } else {
         p.nqb = (T + 63) / 64;
         const long grid = (long)p.nqb * H * B;
