@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtranscodon_hip.so")
+# TC_LIB_PATH points at another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(_HERE, "csrc", "libtranscodon_hip.so")
 
 TC_F32, TC_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_QKV_ROPE = 0, 1, 2, 3

@@ -103,25 +103,39 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bf16_kernel(const AttnParams
 
     // ---- staging: per tile and wave kPieces pieces of K and of V (8 rows x 128 B each) ----
     const int srow = lane >> 3;
-    long k_src[2], v_src[2];      // byte offsets without the key-tile term
+    // Buffer-descriptor loads over this sequence's rows: the lane's row and column offset never
+    // change, the key tile is a scalar offset.  Only a partial last tile builds per-lane offsets
+    // (its rows past the sequence re-read row T-1; their keys are masked by the validity words).
     int s_row[2];
+    unsigned k_col[2], v_col[2];  // byte offset of the lane's 16 bytes inside a row
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) {
         const int r = (wid * kPieces + i) * 8 + srow;
         s_row[i] = r;
-        k_src[i] = (long)(p.E + h * 64) * 2 + (((lane & 7) ^ swz_k(r)) << 4);
-        v_src[i] = (long)(2 * p.E + h * 64) * 2 + (((lane & 7) ^ swz_v(r)) << 4);
+        k_col[i] = (unsigned)(p.E + h * 64) * 2u + (unsigned)(((lane & 7) ^ swz_k(r)) << 4);
+        v_col[i] = (unsigned)(2 * p.E + h * 64) * 2u + (unsigned)(((lane & 7) ^ swz_v(r)) << 4);
     }
+    const __amdgpu_buffer_rsrc_t rsrc_kv = tc_buffer_rsrc(p.qkv + row_base * p.ldq_bytes);
     auto stage = [&](int buf, int kt) {
         char *kb = smem + buf * KV_STAGE_BYTES + wid * kPieces * 1024;
         char *vb = kb + KV_TILE_BYTES;
+        if (kt * 64 + 64 <= p.T) {
+            const unsigned tile_off = (unsigned)((long)kt * 64 * p.ldq_bytes);
 #pragma unroll
-        for (int i = 0; i < kPieces; ++i) {
-            int key = kt * 64 + s_row[i];
-            key = key < p.T ? key : p.T - 1;
-            const char *rowp = p.qkv + (row_base + key) * p.ldq_bytes;
-            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(rowp + k_src[i]), TC_LDS_PTR(kb + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(rowp + v_src[i]), TC_LDS_PTR(vb + i * 1024), 16, 0, 0);
+            for (int i = 0; i < kPieces; ++i) {
+                const unsigned row_off = (unsigned)(s_row[i] * p.ldq_bytes);
+                tc_blds16(rsrc_kv, row_off + k_col[i], tile_off, kb + i * 1024);
+                tc_blds16(rsrc_kv, row_off + v_col[i], tile_off, vb + i * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) {
+                int key = kt * 64 + s_row[i];
+                key = key < p.T ? key : p.T - 1;
+                const unsigned row_off = (unsigned)(key * p.ldq_bytes);
+                tc_blds16(rsrc_kv, row_off + k_col[i], 0u, kb + i * 1024);
+                tc_blds16(rsrc_kv, row_off + v_col[i], 0u, vb + i * 1024);
+            }
         }
     };
 

@@ -163,28 +163,38 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const BwdParams p
     }
 
     const int srow = lane >> 3;
-    long src_kr[2], src_kt[2], src_vr[2];
+    // Buffer-descriptor loads over this sequence's rows: lane offset fixed, key tile scalar; only a
+    // partial last tile builds per-lane offsets (rows past the sequence re-read row T-1).
+    unsigned src_kr[2], src_kt[2], src_vr[2];
     int s_row[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = (wid * 2 + i) * 8 + srow;
         s_row[i] = r;
-        src_kr[i] = (long)(p.E + h * 64) * 2 + (((lane & 7) ^ swz_row(r)) << 4);
-        src_kt[i] = (long)(p.E + h * 64) * 2 + (((lane & 7) ^ swz_tr(r)) << 4);
-        src_vr[i] = (long)(2 * p.E + h * 64) * 2 + (((lane & 7) ^ swz_row(r)) << 4);
+        src_kr[i] = (unsigned)(p.E + h * 64) * 2u + (unsigned)(((lane & 7) ^ swz_row(r)) << 4);
+        src_kt[i] = (unsigned)(p.E + h * 64) * 2u + (unsigned)(((lane & 7) ^ swz_tr(r)) << 4);
+        src_vr[i] = (unsigned)(2 * p.E + h * 64) * 2u + (unsigned)(((lane & 7) ^ swz_row(r)) << 4);
     }
+    const __amdgpu_buffer_rsrc_t rsrc_kv = tc_buffer_rsrc(p.qkv + row_base * p.ldq_bytes);
+    const unsigned kv_row0[2] = {(unsigned)(s_row[0] * p.ldq_bytes), (unsigned)(s_row[1] * p.ldq_bytes)};
     auto stage = [&](int buf, int kt) {
         char *base = smem + buf * DQ_STAGE_BYTES + wid * 2 * 1024;
+        auto pieces = [&](int i, unsigned row_off, unsigned tile_off) {
+            tc_blds16(rsrc_kv, row_off + src_kr[i], tile_off, base + i * 1024);
+            tc_blds16(rsrc_kv, row_off + src_kt[i], tile_off, base + TILE_BYTES + i * 1024);
+            tc_blds16(rsrc_kv, row_off + src_vr[i], tile_off, base + 2 * TILE_BYTES + i * 1024);
+        };
+        if (kt * 64 + 64 <= p.T) {
+            const unsigned tile_off = (unsigned)((long)kt * 64 * p.ldq_bytes);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int key = kt * 64 + s_row[i];
-            key = key < p.T ? key : p.T - 1;
-            const char *rowp = p.qkv + (row_base + key) * p.ldq_bytes;
-            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(rowp + src_kr[i]), TC_LDS_PTR(base + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(rowp + src_kt[i]),
-                                             TC_LDS_PTR(base + TILE_BYTES + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(rowp + src_vr[i]),
-                                             TC_LDS_PTR(base + 2 * TILE_BYTES + i * 1024), 16, 0, 0);
+            for (int i = 0; i < 2; ++i) pieces(i, kv_row0[i], tile_off);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int key = kt * 64 + s_row[i];
+                key = key < p.T ? key : p.T - 1;
+                pieces(i, (unsigned)(key * p.ldq_bytes), 0u);
+            }
         }
     };
 
@@ -352,30 +362,40 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const BwdParams 
     }
 
     const int srow = lane >> 3;
-    int s_row[2], c_row[2], c_tr[2];
+    int s_row[2];
+    unsigned c_row[2], c_tr[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = (wid * 2 + i) * 8 + srow;
         s_row[i] = r;
-        c_row[i] = h * 128 + (((lane & 7) ^ swz_row(r)) << 4);
-        c_tr[i] = h * 128 + (((lane & 7) ^ swz_tr(r)) << 4);
+        c_row[i] = (unsigned)(h * 128 + (((lane & 7) ^ swz_row(r)) << 4));
+        c_tr[i] = (unsigned)(h * 128 + (((lane & 7) ^ swz_tr(r)) << 4));
     }
+    // buffer-descriptor loads as in the dQ kernel: lane offset fixed, query tile scalar
+    const __amdgpu_buffer_rsrc_t rsrc_q = tc_buffer_rsrc(p.qkv + row_base * p.ldq_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_d = tc_buffer_rsrc(p.dout + row_base * p.ldo_bytes);
+    const unsigned q_row0[2] = {(unsigned)(s_row[0] * p.ldq_bytes), (unsigned)(s_row[1] * p.ldq_bytes)};
+    const unsigned d_row0[2] = {(unsigned)(s_row[0] * p.ldo_bytes), (unsigned)(s_row[1] * p.ldo_bytes)};
     auto stage = [&](int buf, int qt) {
         char *stg = smem + buf * DKV_STAGE_BYTES;
         char *base = stg + wid * 2 * 1024;
+        auto pieces = [&](int i, unsigned q_row, unsigned d_row, unsigned q_tile, unsigned d_tile) {
+            tc_blds16(rsrc_q, q_row + c_row[i], q_tile, base + i * 1024);
+            tc_blds16(rsrc_q, q_row + c_tr[i], q_tile, base + TILE_BYTES + i * 1024);
+            tc_blds16(rsrc_d, d_row + c_row[i], d_tile, base + 2 * TILE_BYTES + i * 1024);
+            tc_blds16(rsrc_d, d_row + c_tr[i], d_tile, base + 3 * TILE_BYTES + i * 1024);
+        };
+        if (qt * 64 + 64 <= p.T) {
+            const unsigned q_tile = (unsigned)((long)qt * 64 * p.ldq_bytes), d_tile = (unsigned)((long)qt * 64 * p.ldo_bytes);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int q = qt * 64 + s_row[i];
-            q = q < p.T ? q : p.T - 1;
-            const char *qrow = p.qkv + (row_base + q) * p.ldq_bytes;
-            const char *drow = p.dout + (row_base + q) * p.ldo_bytes;
-            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(qrow + c_row[i]), TC_LDS_PTR(base + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(qrow + c_tr[i]),
-                                             TC_LDS_PTR(base + TILE_BYTES + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(drow + c_row[i]),
-                                             TC_LDS_PTR(base + 2 * TILE_BYTES + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(drow + c_tr[i]),
-                                             TC_LDS_PTR(base + 3 * TILE_BYTES + i * 1024), 16, 0, 0);
+            for (int i = 0; i < 2; ++i) pieces(i, q_row0[i], d_row0[i], q_tile, d_tile);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int q = qt * 64 + s_row[i];
+                q = q < p.T ? q : p.T - 1;
+                pieces(i, (unsigned)(q * p.ldq_bytes), (unsigned)(q * p.ldo_bytes), 0u, 0u);
+            }
         }
         if (wid < 2) {      // wave 0: lse, wave 1: delta (one float per lane)
             int q = qt * 64 + lane;

@@ -18,6 +18,20 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #define TC_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
 #define TC_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 
+#ifdef __HIPCC__
+// A 1-KiB direct-to-LDS piece through a buffer descriptor (buffer_load_dwordx4 ... offen lds):
+// the per-lane part of the address is a 32-bit VGPR that never changes, the moving part a scalar,
+// so a piece costs no vector arithmetic at issue.  Raw buffer, stride 0, no bounds (callers clamp
+// rows themselves); lane_off + uniform_off must stay below 4 GiB.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tc_buffer_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ void tc_blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, unsigned uniform_off,
+                                          char *lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, TC_LDS_PTR(lds_wave_base), 16, (int)lane_off, (int)uniform_off, 0, 0);
+}
+#endif
+
 // ---- error reporting (host) ---------------------------------------------------------
 void tc_set_error(const char *fmt, ...);
 

@@ -320,22 +320,25 @@ __global__ __launch_bounds__(512) void gemm_tn256x_kernel(const TnParams p) {
 
     // staging: a half-tile is 16 pieces of 4 rows x 256 B; this wave moves pieces 2 wid, 2 wid + 1
     const int srow = lane >> 4, schunk = lane & 15;
-    long a_src[2][2], b_src[2][2];               // [half][piece]: byte offset of this lane's 16 bytes in token row 0
+    unsigned a_src[2][2], b_src[2][2];           // [half][piece]: byte offset of this lane's 16 bytes in token row 0
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = (wid * 2 + i) * 4 + srow;
-        const long rc = (long)((schunk ^ swz(r)) << 4);
+        const unsigned rc = (unsigned)((schunk ^ swz(r)) << 4);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            a_src[h][i] = r * p.lda_bytes + (long)(i0 + h * 128) * 2 + rc;
-            b_src[h][i] = r * p.ldb_bytes + (long)(j0 + h * 128) * 2 + rc;
+            a_src[h][i] = (unsigned)(r * p.lda_bytes) + (unsigned)(i0 + h * 128) * 2u + rc;
+            b_src[h][i] = (unsigned)(r * p.ldb_bytes) + (unsigned)(j0 + h * 128) * 2u + rc;
         }
     }
-    auto stage_half = [&](int slot_off, const char *base, long ld_bytes, const long (&src)[2], int kt) {
+    // buffer-descriptor loads: lane offset fixed, token offset scalar (the host keeps both operands below 4 GiB)
+    const __amdgpu_buffer_rsrc_t rsrc_a = tc_buffer_rsrc(p.A), rsrc_b = tc_buffer_rsrc(p.B);
+    auto stage_half = [&](int slot_off, const char *base, long ld_bytes, const unsigned (&src)[2], int kt) {
         char *dst = smem + slot_off + wid * 2048;
-        const char *row0 = base + (long)(k_begin + kt) * KT * ld_bytes;
-        __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(row0 + src[0]), TC_LDS_PTR(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(row0 + src[1]), TC_LDS_PTR(dst + 1024), 16, 0, 0);
+        const unsigned tok_off = (unsigned)((long)(k_begin + kt) * KT * ld_bytes);
+        const __amdgpu_buffer_rsrc_t rsrc = base == p.A ? rsrc_a : rsrc_b;
+        tc_blds16(rsrc, src[0], tok_off, dst);
+        tc_blds16(rsrc, src[1], tok_off, dst + 1024);
     };
 
     // Transposed-read offsets inside a half-tile (row pitch 256 B).  A 16-lane group g = lane >> 4
@@ -556,7 +559,8 @@ extern "C" int tc_gemm_tn(const void *A, int lda, const void *B, int ldb, float 
         static int alt_on = -1;                   // TC_TN_ALT=0 keeps the single-group kernel
         if (alt_on < 0) { const char *e = getenv("TC_TN_ALT"); alt_on = e ? atoi(e) != 0 : 1; }
         // the alternating kernel has no partial stage and wants two k-tiles in every token split
-        if (alt_on && M % KT == 0 && p.nk >= 2 * splits && (long)M * lda * 2 < (1L << 40))
+        if (alt_on && M % KT == 0 && p.nk >= 2 * splits && (long)M * lda * 2 < (1L << 32) &&
+            (long)M * ldb * 2 < (1L << 32))
             hipLaunchKernelGGL(gemm_tn256x_kernel, dim3((I / 256) * (J / 256), splits), dim3(512), alt::LDS_BYTES, s, p);
         else
             hipLaunchKernelGGL(gemm_tn256_kernel, dim3((I / 256) * (J / 256), splits), dim3(512), big::LDS_BYTES, s, p);
