@@ -352,8 +352,9 @@ int tc_encoder_forward(const tc_encoder_desc *desc, const int32_t *tokens, const
 #define TC_PROF_DECODE 5
 #define TC_PROF_NKINDS 6
 /*
- * When enabled, every launch of the selected kernel families is bracketed by HIP
- * events on its own stream.  tc_prof_collect synchronises those events and returns, per
+ * When enabled, every launch of the selected kernel families carries a start and a stop HIP
+ * event on its own dispatch (hipExtLaunchKernelGGL: the kernel's own timestamps, no marker
+ * packets on the stream).  tc_prof_collect synchronises those events and returns, per
  * kind, the launch count, the summed device time in milliseconds and the summed
  * algorithmic work (flops for GEMM/ATTN, bytes for the others) since the last reset.
  */

@@ -489,12 +489,12 @@ static int attn_fwd_impl(int dtype, const void *qkv, int ldq, const uint64_t *ke
         const long grid = (long)p.nqb * H * B;
         TC_REQUIRE(grid < (1L << 31), "tc_attn_fwd: grid too large");
         TC_REQUIRE(p.nw <= kMaxWords, "tc_attn_fwd: T=%d exceeds the bf16 kernel's %d keys", T, kMaxWords * 64);
-        hipLaunchKernelGGL(attn_bf16_kernel, dim3((unsigned)grid), dim3(64 * kWaves), ATTN_LDS_BYTES, s, p);
+        TC_LAUNCH(attn_bf16_kernel, dim3((unsigned)grid), dim3(64 * kWaves), ATTN_LDS_BYTES, s, p);
     } else {
         p.nqb = (T + 63) / 64;
         const long grid = (long)p.nqb * H * B;
         TC_REQUIRE(grid < (1L << 31), "tc_attn_fwd: grid too large");
-        hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)grid), dim3(64), 0, s, p);
+        TC_LAUNCH(attn_f32_kernel, dim3((unsigned)grid), dim3(64), 0, s, p);
     }
     TC_CHECK_LAUNCH("tc_attn_fwd");
     return TC_OK;
@@ -509,10 +509,10 @@ extern "C" int tc_attn_scores(int dtype, const void *qkv, int ldq, const uint8_t
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((T + 255) / 256, T, B * H), block(256);
     if (dtype == TC_BF16)
-        hipLaunchKernelGGL(scores_kernel<uint16_t>, grid, block, 0, s, static_cast<const uint16_t *>(qkv),
+        TC_LAUNCH(scores_kernel<uint16_t>, grid, block, 0, s, static_cast<const uint16_t *>(qkv),
                            (long)ldq, pad_flags, scores, T, H, E);
     else
-        hipLaunchKernelGGL(scores_kernel<float>, grid, block, 0, s, static_cast<const float *>(qkv),
+        TC_LAUNCH(scores_kernel<float>, grid, block, 0, s, static_cast<const float *>(qkv),
                            (long)ldq, pad_flags, scores, T, H, E);
     TC_CHECK_LAUNCH("tc_attn_scores");
     return TC_OK;

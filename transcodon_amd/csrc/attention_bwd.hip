@@ -756,11 +756,11 @@ extern "C" int tc_attn_bwd(int dtype, const void *qkv, int ldq, const uint64_t *
     const long dgrid = (dthreads + 255) / 256;
     TC_REQUIRE(dgrid < (1L << 31), "tc_attn_bwd: grid too large");
     if (dtype == TC_BF16)
-        hipLaunchKernelGGL(delta_kernel<uint16_t>, dim3((unsigned)dgrid), dim3(256), 0, s,
+        TC_LAUNCH(delta_kernel<uint16_t>, dim3((unsigned)dgrid), dim3(256), 0, s,
                            static_cast<const uint16_t *>(out), static_cast<const uint16_t *>(d_out), delta, rows, T,
                            H);
     else
-        hipLaunchKernelGGL(delta_kernel<float>, dim3((unsigned)dgrid), dim3(256), 0, s,
+        TC_LAUNCH(delta_kernel<float>, dim3((unsigned)dgrid), dim3(256), 0, s,
                            static_cast<const float *>(out), static_cast<const float *>(d_out), delta, rows, T, H);
     TC_CHECK_LAUNCH("tc_attn_bwd(delta)");
 
@@ -777,17 +777,17 @@ extern "C" int tc_attn_bwd(int dtype, const void *qkv, int ldq, const uint64_t *
         const long grid = (long)p.nblk * H * B;
         TC_REQUIRE(grid < (1L << 31), "tc_attn_bwd: grid too large");
         TC_REQUIRE(p.nw <= kMaxWords, "tc_attn_bwd: T=%d exceeds the bf16 kernels' %d keys", T, kMaxWords * 64);
-        hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3((unsigned)grid), dim3(256), DQ_LDS_BYTES, s, p);
+        TC_LAUNCH(attn_bwd_dq_bf16_kernel, dim3((unsigned)grid), dim3(256), DQ_LDS_BYTES, s, p);
         TC_CHECK_LAUNCH("tc_attn_bwd(dq)");
-        hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3((unsigned)grid), dim3(256), DKV_LDS_BYTES, s, p);
+        TC_LAUNCH(attn_bwd_dkv_bf16_kernel, dim3((unsigned)grid), dim3(256), DKV_LDS_BYTES, s, p);
         TC_CHECK_LAUNCH("tc_attn_bwd(dkv)");
     } else {
         p.nblk = (T + 63) / 64;
         const long grid = (long)p.nblk * H * B;
         TC_REQUIRE(grid < (1L << 31), "tc_attn_bwd: grid too large");
-        hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, dim3((unsigned)grid), dim3(64), 0, s, p);
+        TC_LAUNCH(attn_bwd_dq_f32_kernel, dim3((unsigned)grid), dim3(64), 0, s, p);
         TC_CHECK_LAUNCH("tc_attn_bwd(dq)");
-        hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, dim3((unsigned)grid), dim3(64), 0, s, p);
+        TC_LAUNCH(attn_bwd_dkv_f32_kernel, dim3((unsigned)grid), dim3(64), 0, s, p);
         TC_CHECK_LAUNCH("tc_attn_bwd(dkv)");
         if (rope_cos)     // the exactness path undoes the rotation with the standalone kernel
             return tc_rope_bwd(dtype, d_qkv, ldg, rope_cos, rope_sin, B * T, T, E, D, q_scale, stream);

@@ -55,15 +55,33 @@ void tc_set_error(const char *fmt, ...);
 static inline bool tc_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // ---- per-kernel-family event timing ---------------------------------------------------
-// A scope object brackets the launches issued between its construction and destruction
-// with two events on `stream` when profiling is enabled; otherwise it does nothing.
+// While profiling is enabled, a scope object names the kernel family and the work (flop or
+// bytes) of the launches issued on this thread between its construction and destruction.  Each
+// TC_LAUNCH inside it attaches a start and a stop event to the dispatch itself
+// (hipExtLaunchKernelGGL): the timestamps come from the kernel's own packet, so timing adds no
+// marker packets to the stream.  The scope's work and one launch count go to its first launch.
 struct TcProfScope {
     int kind;
-    hipStream_t stream;
-    void *slot;
+    double work;
+    bool first, active;
+    TcProfScope *outer;
     TcProfScope(int kind, hipStream_t stream, double work);
     ~TcProfScope();
 };
+// Events for the next launch of the innermost scope of this thread; false when there is none.
+bool tc_prof_launch_events(hipEvent_t *start, hipEvent_t *stop);
+
+#ifdef __HIPCC__
+#include <hip/hip_ext.h>
+#define TC_LAUNCH(kernel, grid, block, shmem, stream, ...)                                             \
+    do {                                                                                               \
+        hipEvent_t tc_e0__ = nullptr, tc_e1__ = nullptr;                                               \
+        if (tc_prof_launch_events(&tc_e0__, &tc_e1__))                                                 \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, tc_e0__, tc_e1__, 0, __VA_ARGS__); \
+        else                                                                                           \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                       \
+    } while (0)
+#endif
 
 // ---- device helpers ---------------------------------------------------------------
 __device__ __forceinline__ float tc_wave_sum(float v) {

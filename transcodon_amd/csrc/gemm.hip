@@ -1371,9 +1371,9 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
                 }
                 attr_set_x = true;
             }
-            hipLaunchKernelGGL((gemm256x_kernel<T, EPI>), dim3(grid), dim3(512), k256x::LDS_BYTES, stream, p);
+            TC_LAUNCH((gemm256x_kernel<T, EPI>), dim3(grid), dim3(512), k256x::LDS_BYTES, stream, p);
         } else {
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+            TC_LAUNCH(kern, dim3(grid), dim3(512), lds, stream, p);
         }
         }
     } else {
@@ -1391,7 +1391,7 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
         }
         p.tiles_m = (p.M + k128::BM - 1) / k128::BM;
         p.tiles_n = p.N / k128::BN;
-        hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(256), k128::LDS_BYTES, stream, p);
+        TC_LAUNCH(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(256), k128::LDS_BYTES, stream, p);
     }
     TC_CHECK_LAUNCH("tc_gemm");
     return TC_OK;

@@ -561,11 +561,11 @@ extern "C" int tc_gemm_tn(const void *A, int lda, const void *B, int ldb, float 
         // the alternating kernel has no partial stage and wants two k-tiles in every token split
         if (alt_on && M % KT == 0 && p.nk >= 2 * splits && (long)M * lda * 2 < (1L << 32) &&
             (long)M * ldb * 2 < (1L << 32))
-            hipLaunchKernelGGL(gemm_tn256x_kernel, dim3((I / 256) * (J / 256), splits), dim3(512), alt::LDS_BYTES, s, p);
+            TC_LAUNCH(gemm_tn256x_kernel, dim3((I / 256) * (J / 256), splits), dim3(512), alt::LDS_BYTES, s, p);
         else
-            hipLaunchKernelGGL(gemm_tn256_kernel, dim3((I / 256) * (J / 256), splits), dim3(512), big::LDS_BYTES, s, p);
+            TC_LAUNCH(gemm_tn256_kernel, dim3((I / 256) * (J / 256), splits), dim3(512), big::LDS_BYTES, s, p);
     } else {
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3((I / 128) * (J / 128), splits), dim3(256), LDS_BYTES, s, p);
+        TC_LAUNCH(gemm_tn_kernel, dim3((I / 128) * (J / 128), splits), dim3(256), LDS_BYTES, s, p);
     }
     TC_CHECK_LAUNCH("tc_gemm_tn");
     return TC_OK;
@@ -583,10 +583,10 @@ extern "C" int tc_colsum(int dtype, const void *x, int ld, void *bf16_copy, int 
     const int rows_per_block = 512;
     const dim3 grid((N + 63) / 64, (M + rows_per_block - 1) / rows_per_block), block(256);
     if (dtype == TC_BF16)
-        hipLaunchKernelGGL(colsum_kernel<uint16_t>, grid, block, 0, s, static_cast<const uint16_t *>(x), (long)ld,
+        TC_LAUNCH(colsum_kernel<uint16_t>, grid, block, 0, s, static_cast<const uint16_t *>(x), (long)ld,
                            static_cast<uint16_t *>(nullptr), 0L, colsum, M, N, rows_per_block);
     else
-        hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, static_cast<const float *>(x), (long)ld,
+        TC_LAUNCH(colsum_kernel<float>, grid, block, 0, s, static_cast<const float *>(x), (long)ld,
                            static_cast<uint16_t *>(bf16_copy), (long)ld_copy, colsum, M, N, rows_per_block);
     TC_CHECK_LAUNCH("tc_colsum");
     return TC_OK;

@@ -328,7 +328,7 @@ extern "C" int tc_mean_pool(const float *rep, const int32_t *start, const int32_
                             int B, int T, int E, void *stream) {
     TC_REQUIRE(rep && start && len && pooled, "tc_mean_pool: null operand");
     TC_REQUIRE(B > 0 && T > 0 && E > 0 && B <= 65535, "tc_mean_pool: bad shape B=%d T=%d E=%d", B, T, E);
-    hipLaunchKernelGGL(mean_pool_kernel, dim3((E + 255) / 256, B), dim3(256), 0,
+    TC_LAUNCH(mean_pool_kernel, dim3((E + 255) / 256, B), dim3(256), 0,
                        static_cast<hipStream_t>(stream), rep, start, len, pooled, T, E);
     TC_CHECK_LAUNCH("tc_mean_pool");
     return TC_OK;
@@ -346,7 +346,7 @@ extern "C" int tc_embed_fwd(const int32_t *tokens, const int32_t *species, const
     TC_REQUIRE(M < (1L << 31), "tc_embed_fwd: too many rows");
     hipStream_t s = static_cast<hipStream_t>(stream);
     TcProfScope prof(TC_PROF_EMBED, s, (double)M * (4.0 + 4.0 * E));
-    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, tokens, species,
+    TC_LAUNCH(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, tokens, species,
                        tok_table, species_table, x, pad_flags, bad_index, (int)M, T, E, vocab,
                        n_species, pad_idx);
     TC_CHECK_LAUNCH("tc_embed_fwd");
@@ -367,7 +367,7 @@ extern "C" int tc_layernorm_fwd(const float *x, const float *gamma, const float 
     const dim3 grid((M + 3) / 4), block(256);
     uint16_t *ob = static_cast<uint16_t *>(out_bf16);
     const int nch = (E + 255) / 256;
-#define TC_LN(N) hipLaunchKernelGGL(layernorm_kernel<N>, grid, block, 0, s, x, gamma, beta, out_f32, ob, M, E, eps)
+#define TC_LN(N) TC_LAUNCH(layernorm_kernel<N>, grid, block, 0, s, x, gamma, beta, out_f32, ob, M, E, eps)
     switch (nch) {
         case 1: TC_LN(1); break;
         case 2: TC_LN(2); break;
@@ -384,7 +384,7 @@ extern "C" int tc_key_mask_words(const uint8_t *pad_flags, uint64_t *words, int 
                                  void *stream) {
     TC_REQUIRE(pad_flags && words && B > 0 && T > 0, "tc_key_mask_words: bad arguments");
     const int nw = (T + 63) / 64;
-    hipLaunchKernelGGL(key_mask_kernel, dim3(nw, B), dim3(64), 0, static_cast<hipStream_t>(stream),
+    TC_LAUNCH(key_mask_kernel, dim3(nw, B), dim3(64), 0, static_cast<hipStream_t>(stream),
                        pad_flags, words, T, nw);
     TC_CHECK_LAUNCH("tc_key_mask_words");
     return TC_OK;
@@ -406,7 +406,7 @@ extern "C" int tc_head_logits_fwd(int dtype, const void *g, int ldg, int col0, c
     const dim3 grid((M + 3) / 4), block(256);
     const int nch = (E + 255) / 256;
 #define TC_HEAD(TY, N)                                                                          \
-    hipLaunchKernelGGL((head_kernel<TY, N>), grid, block, 0, s, static_cast<const TY *>(g), ldg, \
+    TC_LAUNCH((head_kernel<TY, N>), grid, block, 0, s, static_cast<const TY *>(g), ldg, \
                        col0, gamma, beta, W, bias, out, M, E, V, eps)
     if (dtype == TC_BF16) {
         switch (nch) {
@@ -436,7 +436,7 @@ extern "C" int tc_codon_decode(const float *logits, int ldl, const uint8_t *aa,
     if (n_aa_total == 0) return TC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     TcProfScope prof(TC_PROF_DECODE, s, (double)n_aa_total * (120.0 + 3.0 + 1.0));
-    hipLaunchKernelGGL(decode_kernel, dim3((n_aa_total + 255) / 256), dim3(256), 0, s, logits, ldl, aa,
+    TC_LAUNCH(decode_kernel, dim3((n_aa_total + 255) / 256), dim3(256), 0, s, logits, ldl, aa,
                        aa_off, row0, bases, n_seq, n_aa_total);
     TC_CHECK_LAUNCH("tc_codon_decode");
     return TC_OK;
@@ -447,7 +447,7 @@ extern "C" int tc_ce_loss_fwd_bwd(const float *logits, const int32_t *labels, fl
                                   void *stream) {
     TC_REQUIRE(logits && labels && loss_sum && count, "tc_ce_loss_fwd_bwd: null operand");
     TC_REQUIRE(M > 0 && V > 0 && V <= 64, "tc_ce_loss_fwd_bwd: bad shape M=%d V=%d", M, V);
-    hipLaunchKernelGGL(ce_kernel, dim3((M + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+    TC_LAUNCH(ce_kernel, dim3((M + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
                        logits, labels, loss_sum, count, dlogits, grad_scale, M, V);
     TC_CHECK_LAUNCH("tc_ce_loss_fwd_bwd");
     return TC_OK;

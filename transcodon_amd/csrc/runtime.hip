@@ -11,8 +11,8 @@ thread_local char g_err[512] = "";
 struct ProfSlot {
     hipEvent_t start, stop;
     int kind;
+    int count;          // 1 for the first launch of a scope, 0 for its further launches
     double work;
-    bool used;
 };
 
 struct ProfState {
@@ -37,9 +37,22 @@ void tc_set_error(const char *fmt, ...) {
 extern "C" const char *tc_last_error(void) { return g_err; }
 extern "C" int tc_version(void) { return TC_VERSION; }
 
-TcProfScope::TcProfScope(int kind_, hipStream_t stream_, double work)
-    : kind(kind_), stream(stream_), slot(nullptr) {
-    if (!g_prof.enabled) return;
+static thread_local TcProfScope *t_scope = nullptr;
+
+TcProfScope::TcProfScope(int kind_, hipStream_t, double work_)
+    : kind(kind_), work(work_), first(true), active(g_prof.enabled), outer(nullptr) {
+    if (!active) return;
+    outer = t_scope;
+    t_scope = this;
+}
+
+TcProfScope::~TcProfScope() {
+    if (active) t_scope = outer;
+}
+
+bool tc_prof_launch_events(hipEvent_t *start, hipEvent_t *stop) {
+    TcProfScope *sc = t_scope;
+    if (!sc) return false;
     std::lock_guard<std::mutex> lk(g_prof.mu);
     ProfSlot *s;
     if (!g_prof.free_slots.empty()) {
@@ -47,30 +60,32 @@ TcProfScope::TcProfScope(int kind_, hipStream_t stream_, double work)
         g_prof.free_slots.pop_back();
     } else {
         s = new ProfSlot();
-        if (hipEventCreate(&s->start) != hipSuccess || hipEventCreate(&s->stop) != hipSuccess) {
+        if (hipEventCreate(&s->start) != hipSuccess) {
             delete s;
-            return;
+            return false;
+        }
+        if (hipEventCreate(&s->stop) != hipSuccess) {
+            (void)hipEventDestroy(s->start);
+            delete s;
+            return false;
         }
     }
-    s->kind = kind;
-    s->work = work;
-    s->used = hipEventRecord(s->start, stream) == hipSuccess;
+    s->kind = sc->kind;
+    s->count = sc->first ? 1 : 0;
+    s->work = sc->first ? sc->work : 0.0;
+    sc->first = false;
     g_prof.slots.push_back(s);
-    slot = s;
-}
-
-TcProfScope::~TcProfScope() {
-    if (!slot) return;
-    ProfSlot *s = static_cast<ProfSlot *>(slot);
-    if (s->used) s->used = hipEventRecord(s->stop, stream) == hipSuccess;
+    *start = s->start;
+    *stop = s->stop;
+    return true;
 }
 
 static void prof_drain_locked() {
     for (ProfSlot *s : g_prof.slots) {
-        if (s->used && hipEventSynchronize(s->stop) == hipSuccess) {
+        if (hipEventSynchronize(s->stop) == hipSuccess) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, s->start, s->stop) == hipSuccess) {
-                g_prof.launches[s->kind] += 1;
+                g_prof.launches[s->kind] += s->count;
                 g_prof.ms[s->kind] += ms;
                 g_prof.work[s->kind] += s->work;
             }

@@ -448,15 +448,15 @@ extern "C" int tc_transpose_cast(int in_dtype, int out_dtype, const void *in, in
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((ldt + 63) / 64, (N + 63) / 64), block(256);
     if (in_dtype == TC_F32 && out_dtype == TC_F32)
-        hipLaunchKernelGGL((transpose_kernel<float, float>), grid, block, 0, s, static_cast<const float *>(in),
+        TC_LAUNCH((transpose_kernel<float, float>), grid, block, 0, s, static_cast<const float *>(in),
                            (long)ld_in, static_cast<float *>(out_t), (long)ldt, static_cast<float *>(out_rowmajor),
                            (long)ld_rm, colsum, M, N);
     else if (in_dtype == TC_F32)
-        hipLaunchKernelGGL((transpose_kernel<float, uint16_t>), grid, block, 0, s, static_cast<const float *>(in),
+        TC_LAUNCH((transpose_kernel<float, uint16_t>), grid, block, 0, s, static_cast<const float *>(in),
                            (long)ld_in, static_cast<uint16_t *>(out_t), (long)ldt,
                            static_cast<uint16_t *>(out_rowmajor), (long)ld_rm, colsum, M, N);
     else
-        hipLaunchKernelGGL((transpose_kernel<uint16_t, uint16_t>), grid, block, 0, s,
+        TC_LAUNCH((transpose_kernel<uint16_t, uint16_t>), grid, block, 0, s,
                            static_cast<const uint16_t *>(in), (long)ld_in, static_cast<uint16_t *>(out_t), (long)ldt,
                            static_cast<uint16_t *>(out_rowmajor), (long)ld_rm, colsum, M, N);
     TC_CHECK_LAUNCH("tc_transpose_cast");
@@ -466,7 +466,7 @@ extern "C" int tc_transpose_cast(int in_dtype, int out_dtype, const void *in, in
 extern "C" int tc_reduce_slabs(const float *slabs, float *out, int S, long n, int accumulate, void *stream) {
     TC_REQUIRE(slabs && out && S >= 1 && n > 0 && n % 4 == 0, "tc_reduce_slabs: bad arguments");
     TC_REQUIRE(tc_aligned16(slabs) && tc_aligned16(out), "tc_reduce_slabs: misaligned operand");
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0,
+    TC_LAUNCH(reduce_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), slabs, out, S, n, accumulate);
     TC_CHECK_LAUNCH("tc_reduce_slabs");
     return TC_OK;
@@ -487,7 +487,7 @@ extern "C" int tc_layernorm_bwd(int x_dtype, const void *x, int ldx, const float
     if (blocks > 512) blocks = 512;
     const int nch = (E + 255) / 256;
 #define TC_LNB(TX, N)                                                                                     \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<TX, N>), dim3(blocks), dim3(256), 0, s, static_cast<const TX *>(x), \
+    TC_LAUNCH((layernorm_bwd_kernel<TX, N>), dim3(blocks), dim3(256), 0, s, static_cast<const TX *>(x), \
                        (long)ldx, gamma, dy, dx, accumulate, dgamma, dbeta, M, E, eps)
     if (x_dtype == TC_F32) {
         switch (nch) { case 1: TC_LNB(float, 1); break; case 2: TC_LNB(float, 2); break;
@@ -507,10 +507,10 @@ extern "C" int tc_dgelu(int dtype, const float *dy, const void *u, void *out, lo
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((n / 4 + 255) / 256)), block(256);
     if (dtype == TC_F32)
-        hipLaunchKernelGGL(dgelu_kernel<float>, grid, block, 0, s, dy, static_cast<const float *>(u),
+        TC_LAUNCH(dgelu_kernel<float>, grid, block, 0, s, dy, static_cast<const float *>(u),
                            static_cast<float *>(out), n);
     else
-        hipLaunchKernelGGL(dgelu_kernel<uint16_t>, grid, block, 0, s, dy, static_cast<const uint16_t *>(u),
+        TC_LAUNCH(dgelu_kernel<uint16_t>, grid, block, 0, s, dy, static_cast<const uint16_t *>(u),
                            static_cast<uint16_t *>(out), n);
     TC_CHECK_LAUNCH("tc_dgelu");
     return TC_OK;
@@ -528,7 +528,7 @@ extern "C" int tc_head_logits_bwd(int dtype, const void *g, int ldg, int col0, c
     if (blocks > 512) blocks = 512;
     const int nch = (E + 255) / 256;
 #define TC_HB(TY, N, VV)                                                                                   \
-    hipLaunchKernelGGL((head_bwd_kernel<TY, N, VV>), dim3(blocks), dim3(256), 0, s, static_cast<const TY *>(g), \
+    TC_LAUNCH((head_bwd_kernel<TY, N, VV>), dim3(blocks), dim3(256), 0, s, static_cast<const TY *>(g), \
                        ldg, col0, gamma, beta, W, dlogits, d_ln, dW, dbias, M, E, eps)
 #define TC_HB_V(TY, N) do { if (V == 3) TC_HB(TY, N, 3); else TC_HB(TY, N, 10); } while (0)
     if (dtype == TC_F32) {
@@ -548,7 +548,7 @@ extern "C" int tc_embed_bwd(const int32_t *tokens, const int32_t *species, const
     TC_REQUIRE(tokens && species && dx && d_tok_table && d_species_table, "tc_embed_bwd: null operand");
     TC_REQUIRE(B > 0 && T > 0 && E > 0 && vocab > 0 && (size_t)vocab * E * 4 <= 64 * 1024,
                "tc_embed_bwd: bad shape (vocab*E*4 must fit 64 KiB of LDS)");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B, (T + kEmbedBwdRows - 1) / kEmbedBwdRows), dim3(256), (size_t)vocab * E * 4, static_cast<hipStream_t>(stream),
+    TC_LAUNCH(embed_bwd_kernel, dim3(B, (T + kEmbedBwdRows - 1) / kEmbedBwdRows), dim3(256), (size_t)vocab * E * 4, static_cast<hipStream_t>(stream),
                        tokens, species, dx, d_tok_table, d_species_table, T, E, vocab, n_species, pad_idx);
     TC_CHECK_LAUNCH("tc_embed_bwd");
     return TC_OK;
@@ -564,10 +564,10 @@ extern "C" int tc_rope_bwd(int dtype, void *dqkv, int ld, const float *rope_cos,
     const long n = (long)M * E;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (dtype == TC_F32)
-        hipLaunchKernelGGL(rope_bwd_kernel<float>, grid, block, 0, s, static_cast<float *>(dqkv), (long)ld, rope_cos,
+        TC_LAUNCH(rope_bwd_kernel<float>, grid, block, 0, s, static_cast<float *>(dqkv), (long)ld, rope_cos,
                            rope_sin, M, T, E, head_dim, q_scale);
     else
-        hipLaunchKernelGGL(rope_bwd_kernel<uint16_t>, grid, block, 0, s, static_cast<uint16_t *>(dqkv), (long)ld,
+        TC_LAUNCH(rope_bwd_kernel<uint16_t>, grid, block, 0, s, static_cast<uint16_t *>(dqkv), (long)ld,
                            rope_cos, rope_sin, M, T, E, head_dim, q_scale);
     TC_CHECK_LAUNCH("tc_rope_bwd");
     return TC_OK;
@@ -596,7 +596,7 @@ extern "C" int tc_mlm_loss(const float *logits, const int32_t *labels, const flo
     const long n_dl = dlogits ? (long)M * V : 0, n_ds = dstruct_logits ? (long)M * S : 0;
     long n = n_dl > n_ds ? n_dl : n_ds;
     if (n < 1) n = 1;
-    hipLaunchKernelGGL(mlm_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, stats, counts, loss,
+    TC_LAUNCH(mlm_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, stats, counts, loss,
                        dlogits, n_dl, dstruct_logits, n_ds, struct_weight, upstream);
     TC_CHECK_LAUNCH("tc_mlm_loss");
     return TC_OK;
@@ -609,7 +609,7 @@ extern "C" int tc_adamw_step(float *param, const float *grad, float *exp_avg, fl
     TC_REQUIRE(tc_aligned16(param) && tc_aligned16(grad) && tc_aligned16(exp_avg) && tc_aligned16(exp_avg_sq),
                "tc_adamw_step: operands must be 16-byte aligned");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0,
+    TC_LAUNCH(adamw_kernel, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
                        weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
     TC_CHECK_LAUNCH("tc_adamw_step");
@@ -625,7 +625,7 @@ extern "C" int tc_mlm_mask(const int32_t *tokens, const int32_t *lens, int32_t *
     TC_REQUIRE(mask_proportion >= 0 && mask_proportion <= 1 && mask_percent >= 0 && leave_percent >= 0 &&
                    mask_percent + leave_percent <= 1.0,
                "tc_mlm_mask: bad proportions");
-    hipLaunchKernelGGL(mlm_mask_kernel, dim3(B), dim3(256), (size_t)T * 4, static_cast<hipStream_t>(stream), tokens, lens,
+    TC_LAUNCH(mlm_mask_kernel, dim3(B), dim3(256), (size_t)T * 4, static_cast<hipStream_t>(stream), tokens, lens,
                        tokens_out, labels, struct_labels, T, seed, mask_proportion, mask_percent, leave_percent, mask_idx,
                        n_coding, coding_ids);
     TC_CHECK_LAUNCH("tc_mlm_mask");
