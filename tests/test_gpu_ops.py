@@ -323,6 +323,17 @@ def test_attention_online_softmax_rescale():
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
 
 
+def test_attention_rejects_sequences_beyond_the_bf16_limit():
+    """The bf16 kernels keep one validity word per 64 keys in LDS: 8192 keys at most; the call
+    must fail with an error instead of reading past the table."""
+    T, H = 8192 + 64, 1
+    qkv = torch.zeros(T, 3 * 64, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(_lib.HipLibraryError):
+        ops.attention(qkv, 1, T, H)
+    out = ops.attention(torch.zeros(8192, 3 * 64, device=DEV, dtype=torch.bfloat16), 1, 8192, H)   # the limit itself runs
+    assert torch.isfinite(out.float()).all()
+
+
 # ---------------------------------------------------------------- decode and loss
 def test_decode_known_answers(golden_dir):
     kats = json.load(open(os.path.join(golden_dir, "decode_kat.json")))

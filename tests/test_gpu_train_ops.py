@@ -78,13 +78,16 @@ def test_gelu_save_and_dgelu_epilogues(dtype):
     np.testing.assert_allclose(du2.float().cpu().numpy(), uu.grad.numpy(), **tol)
 
 
-@pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("xdtype,dydtype", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
+                                            (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])
 @pytest.mark.parametrize("E", [128, 768])
-def test_layernorm_backward(xdtype, E):
+def test_layernorm_backward(xdtype, dydtype, E):
     M = 777
     x, g, b, dy = _rand(M, E, seed=10, scale=2.0) + 0.3, _rand(E, seed=11) + 1.0, _rand(E, seed=12), _rand(M, E, seed=13)
     if xdtype == torch.bfloat16:
         x = _bf(x)
+    if dydtype == torch.bfloat16:
+        dy = _bf(dy)                      # the reference then sees exactly the values the kernel reads
     with torch.enable_grad():
         xx, gg, bb = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
         torch.nn.functional.layer_norm(xx, (E,), gg, bb, 1e-5).backward(dy)
@@ -92,11 +95,11 @@ def test_layernorm_backward(xdtype, E):
     dbet = torch.zeros(E, device=DEV)
     carry = _rand(M, E, seed=14)
     dx = carry.to(DEV).clone()
-    ops.layernorm_bwd(x.to(DEV, xdtype), g.to(DEV), dy.to(DEV), dgam, dbet, dx=dx, accumulate=True)
+    ops.layernorm_bwd(x.to(DEV, xdtype), g.to(DEV), dy.to(DEV, dydtype), dgam, dbet, dx=dx, accumulate=True)
     np.testing.assert_allclose(dx.cpu().numpy(), (carry + xx.grad).numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(dgam.cpu().numpy(), gg.grad.numpy(), rtol=1e-3, atol=2e-3)
     np.testing.assert_allclose(dbet.cpu().numpy(), bb.grad.numpy(), rtol=1e-3, atol=2e-3)
-    dx2 = ops.layernorm_bwd(x.to(DEV, xdtype), g.to(DEV), dy.to(DEV), dgam, dbet)
+    dx2 = ops.layernorm_bwd(x.to(DEV, xdtype), g.to(DEV), dy.to(DEV, dydtype), dgam, dbet)
     np.testing.assert_allclose(dx2.cpu().numpy(), xx.grad.numpy(), rtol=1e-4, atol=1e-4)
 
 

@@ -320,10 +320,12 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
                              stream));
         TC_TRY(linear_wgrad(d, w, dt, w.wide, w.ld_f, nullptr, sv.h2, E, M, F, E, lg.w_fc1, lg.b_fc1, stream));
         TC_TRY(transpose_weight(d, w, lw.w_fc1, F, E, stream));
-        TC_TRY(tc_gemm_train(dt, TC_EPI_PLAIN_F32, w.wide, w.ld_f, w.wt, nullptr, nullptr, w.t0, nullptr, E, M, E, F, 1,
-                             stream));
-        TC_TRY(tc_layernorm_bwd(TC_F32, sv.x_mid, E, lw.ln2_g, w.t0, dx, 1, lg.ln2_g, lg.ln2_b, M, E, d->ln_eps,
-                                stream));
+        // the gradient handed to a LayerNorm comes out of the product in the compute type (bf16: what a
+        // bf16 Linear returns under autocast), half the bytes for the product to write and the LayerNorm to read
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS, w.wide, w.ld_f, w.wt, nullptr, nullptr, w.t0, E, M, E, F, 0.f, nullptr, nullptr, 0,
+                       0, stream));
+        TC_TRY(tc_layernorm_bwd_dy(TC_F32, sv.x_mid, E, lw.ln2_g, dt, w.t0, E, dx, 1, lg.ln2_g, lg.ln2_b, M, E,
+                                   d->ln_eps, stream));
         // ---- attention block: x_mid = x_in + out_proj(attn(rope(qkv(LN1(x_in))))) ----
         TC_TRY(linear_wgrad(d, w, TC_F32, dx, E, w.dyb, sv.ao, E, M, E, E, lg.w_o, lg.b_o, stream));
         TC_TRY(transpose_weight(d, w, lw.w_o, E, E, stream));
@@ -334,10 +336,10 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
                            lw.rope_sin, 0.125f, B, T, d->H, 64, stream));
         TC_TRY(linear_wgrad(d, w, dt, w.wide, 3 * E, nullptr, sv.h1, E, M, 3 * E, E, lg.w_qkv, lg.b_qkv, stream));
         TC_TRY(transpose_weight(d, w, lw.w_qkv, 3 * E, E, stream));
-        TC_TRY(tc_gemm_train(dt, TC_EPI_PLAIN_F32, w.wide, 3 * E, w.wt, nullptr, nullptr, w.t0, nullptr, E, M, E, 3 * E,
-                             1, stream));
-        TC_TRY(tc_layernorm_bwd(TC_F32, sv.x_in, E, lw.ln1_g, w.t0, dx, 1, lg.ln1_g, lg.ln1_b, M, E, d->ln_eps,
-                                stream));
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS, w.wide, 3 * E, w.wt, nullptr, nullptr, w.t0, E, M, E, 3 * E, 0.f, nullptr, nullptr,
+                       0, 0, stream));
+        TC_TRY(tc_layernorm_bwd_dy(TC_F32, sv.x_in, E, lw.ln1_g, dt, w.t0, E, dx, 1, lg.ln1_g, lg.ln1_b, M, E,
+                                   d->ln_eps, stream));
         if (ready) ready(l, user);       // every kernel that writes layer l's gradients is enqueued
     }
     TC_TRY(tc_embed_bwd(tokens, species, dx, g->tok_table, g->species_table, B, T, E, d->vocab, d->n_species,

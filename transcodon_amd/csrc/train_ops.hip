@@ -70,17 +70,21 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restri
 }
 
 // ---- LayerNorm backward ----------------------------------------------------------------------
-template <typename TX, int NCH>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX *__restrict__ x, long ldx,
+// One row per wave and iteration, three dependent wave reductions per row: the kernel lives on
+// waves in flight, so a workgroup is 8 waves (two workgroups, 16 waves per CU) while the number
+// of workgroups, and with it the global atomics at the end, stays small.
+constexpr int kLnbWaves = 8;
+template <typename TX, typename TDY, int NCH>
+__global__ __launch_bounds__(64 * kLnbWaves) void layernorm_bwd_kernel(const TX *__restrict__ x, long ldx,
                                                             const float *__restrict__ gamma,
-                                                            const float *__restrict__ dy,
+                                                            const TDY *__restrict__ dy, long lddy,
                                                             float *__restrict__ dx, int accumulate,
                                                             float *__restrict__ dgamma,
                                                             float *__restrict__ dbeta, int M, int E,
                                                             float eps) {
     __shared__ float red[2][NCH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 2 * NCH * 256; i += 256) (&red[0][0])[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * NCH * 256; i += 64 * kLnbWaves) (&red[0][0])[i] = 0.f;
     __syncthreads();
     f32x4 g_[NCH], dg[NCH], db[NCH];
 #pragma unroll
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX *__restrict
         dg[c] = f32x4{0, 0, 0, 0};
         db[c] = f32x4{0, 0, 0, 0};
     }
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * kLnbWaves + wave; row < M; row += gridDim.x * kLnbWaves) {
         f32x4 xv[NCH], dyv[NCH];
         float s = 0.f;
 #pragma unroll
@@ -104,7 +108,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX *__restrict
                     const u32x2 w = *reinterpret_cast<const u32x2 *>(px);
                     xv[c] = f32x4{tc_bf16_lo(w[0]), tc_bf16_hi(w[0]), tc_bf16_lo(w[1]), tc_bf16_hi(w[1])};
                 }
-                dyv[c] = *reinterpret_cast<const f32x4 *>(dy + (long)row * E + col);
+                const TDY *pdy = dy + (long)row * lddy + col;
+                if constexpr (sizeof(TDY) == 4) {
+                    dyv[c] = *reinterpret_cast<const f32x4 *>(pdy);
+                } else {
+                    const u32x2 w = *reinterpret_cast<const u32x2 *>(pdy);
+                    dyv[c] = f32x4{tc_bf16_lo(w[0]), tc_bf16_hi(w[0]), tc_bf16_lo(w[1]), tc_bf16_hi(w[1])};
+                }
             } else {
                 xv[c] = f32x4{0, 0, 0, 0};
                 dyv[c] = f32x4{0, 0, 0, 0};
@@ -165,9 +175,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX *__restrict
             atomicAdd(&red[0][c * 256 + lane * 4 + j], dg[c][j]);
             atomicAdd(&red[1][c * 256 + lane * 4 + j], db[c][j]);
         }
-    (void)wave;
     __syncthreads();
-    for (int col = threadIdx.x; col < E; col += 256) {
+    for (int col = threadIdx.x; col < E; col += 64 * kLnbWaves) {
         atomicAdd(dgamma + col, red[0][col]);
         atomicAdd(dbeta + col, red[1][col]);
     }
@@ -472,33 +481,47 @@ extern "C" int tc_reduce_slabs(const float *slabs, float *out, int S, long n, in
     return TC_OK;
 }
 
-extern "C" int tc_layernorm_bwd(int x_dtype, const void *x, int ldx, const float *gamma, const float *dy,
-                                float *dx, int accumulate, float *dgamma, float *dbeta, int M, int E, float eps,
-                                void *stream) {
+extern "C" int tc_layernorm_bwd_dy(int x_dtype, const void *x, int ldx, const float *gamma, int dy_dtype,
+                                   const void *dy, int lddy, float *dx, int accumulate, float *dgamma, float *dbeta,
+                                   int M, int E, float eps, void *stream) {
     TC_REQUIRE(x && gamma && dy && dx && dgamma && dbeta, "tc_layernorm_bwd: null operand");
-    TC_REQUIRE(M > 0 && E > 0 && E % 4 == 0 && E <= 1024 && ldx >= E, "tc_layernorm_bwd: bad shape M=%d E=%d", M, E);
-    TC_REQUIRE(x_dtype == TC_F32 || x_dtype == TC_BF16, "tc_layernorm_bwd: bad dtype");
-    TC_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x % (x_dtype == TC_F32 ? 16 : 8)) == 0 && tc_aligned16(dy) && tc_aligned16(dx),
-               "tc_layernorm_bwd: x rows must be 4-element aligned, dy and dx 16-byte aligned");
+    TC_REQUIRE(M > 0 && E > 0 && E % 4 == 0 && E <= 1024 && ldx >= E && lddy >= E,
+               "tc_layernorm_bwd: bad shape M=%d E=%d", M, E);
+    TC_REQUIRE((x_dtype == TC_F32 || x_dtype == TC_BF16) && (dy_dtype == TC_F32 || dy_dtype == TC_BF16),
+               "tc_layernorm_bwd: bad dtype");
+    TC_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && ((uintptr_t)x % (x_dtype == TC_F32 ? 16 : 8)) == 0 &&
+                   ((uintptr_t)dy % (dy_dtype == TC_F32 ? 16 : 8)) == 0 && tc_aligned16(dx),
+               "tc_layernorm_bwd: x and dy rows must be 4-element aligned, dx 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // every workgroup ends with 2E global atomics onto the same addresses: 512 workgroups (two per
-    // CU) measured 86 us at M = 32768, E = 768 against 123 us with 2048 and 112 us with 256
-    int blocks = (M + 3) / 4;
-    if (blocks > 512) blocks = 512;
+    // Waves in flight, not workgroup shape, set the pace (M = 65536, E = 768, accumulating; the same
+    // totals as 4-, 8- or 16-wave workgroups give the same times): 2048 waves 169 us with f32 dy and
+    // 187 us with bf16 dy, 4096 waves 182 / 160 us, 8192 waves 206 / 190 us, 1024 waves 245 / 290 us.
+    // Every workgroup also ends with 2E global atomics onto the same addresses.
+    const int cap = dy_dtype == TC_F32 ? 256 : 512;
+    int blocks = (M + kLnbWaves - 1) / kLnbWaves;
+    if (blocks > cap) blocks = cap;
     const int nch = (E + 255) / 256;
-#define TC_LNB(TX, N)                                                                                     \
-    TC_LAUNCH((layernorm_bwd_kernel<TX, N>), dim3(blocks), dim3(256), 0, s, static_cast<const TX *>(x), \
-                       (long)ldx, gamma, dy, dx, accumulate, dgamma, dbeta, M, E, eps)
+#define TC_LNB(TX, TDY, N)                                                                                      \
+    TC_LAUNCH((layernorm_bwd_kernel<TX, TDY, N>), dim3(blocks), dim3(64 * kLnbWaves), 0, s, static_cast<const TX *>(x), \
+              (long)ldx, gamma, static_cast<const TDY *>(dy), (long)lddy, dx, accumulate, dgamma, dbeta, M, E, eps)
+#define TC_LNB_N(TX, TDY)                                                                          \
+    switch (nch) { case 1: TC_LNB(TX, TDY, 1); break; case 2: TC_LNB(TX, TDY, 2); break;           \
+                   case 3: TC_LNB(TX, TDY, 3); break; default: TC_LNB(TX, TDY, 4); break; }
     if (x_dtype == TC_F32) {
-        switch (nch) { case 1: TC_LNB(float, 1); break; case 2: TC_LNB(float, 2); break;
-                       case 3: TC_LNB(float, 3); break; default: TC_LNB(float, 4); break; }
+        if (dy_dtype == TC_F32) { TC_LNB_N(float, float) } else { TC_LNB_N(float, uint16_t) }
     } else {
-        switch (nch) { case 1: TC_LNB(uint16_t, 1); break; case 2: TC_LNB(uint16_t, 2); break;
-                       case 3: TC_LNB(uint16_t, 3); break; default: TC_LNB(uint16_t, 4); break; }
+        if (dy_dtype == TC_F32) { TC_LNB_N(uint16_t, float) } else { TC_LNB_N(uint16_t, uint16_t) }
     }
+#undef TC_LNB_N
 #undef TC_LNB
     TC_CHECK_LAUNCH("tc_layernorm_bwd");
     return TC_OK;
+}
+
+extern "C" int tc_layernorm_bwd(int x_dtype, const void *x, int ldx, const float *gamma, const float *dy,
+                                float *dx, int accumulate, float *dgamma, float *dbeta, int M, int E, float eps,
+                                void *stream) {
+    return tc_layernorm_bwd_dy(x_dtype, x, ldx, gamma, TC_F32, dy, E, dx, accumulate, dgamma, dbeta, M, E, eps, stream);
 }
 
 extern "C" int tc_dgelu(int dtype, const float *dy, const void *u, void *out, long n, void *stream) {

@@ -207,16 +207,17 @@ def reduce_slabs(slabs, out=None, accumulate=False):
 
 
 def layernorm_bwd(x, gamma, dy, dgamma, dbeta, dx=None, accumulate=False, eps=1e-5):
-    """x may be a column slice of a wider buffer (row stride = its leading dimension)."""
+    """x and dy may be column slices of wider buffers (row stride = leading dimension); dy f32 or bf16."""
     _dev(gamma, dy, dgamma, dbeta, dx)
-    if not x.is_cuda or x.stride(1) != 1:
-        raise ValueError("x must be a GPU tensor with unit column stride")
+    if not x.is_cuda or x.stride(1) != 1 or dy.stride(1) != 1:
+        raise ValueError("x must be a GPU tensor, x and dy with unit column stride")
     M, E = dy.shape
     if dx is None:
         dx = torch.empty(M, E, dtype=torch.float32, device=dy.device)
         accumulate = False
-    check(_lib.load().tc_layernorm_bwd(_dt(x), _p(x), x.stride(0), _p(gamma), _p(dy), _p(dx), int(accumulate),
-                                       _p(dgamma), _p(dbeta), M, E, eps, _stream()), "tc_layernorm_bwd")
+    check(_lib.load().tc_layernorm_bwd_dy(_dt(x), _p(x), x.stride(0), _p(gamma), _dt(dy), _p(dy), dy.stride(0), _p(dx),
+                                          int(accumulate), _p(dgamma), _p(dbeta), M, E, eps, _stream()),
+          "tc_layernorm_bwd")
     return dx
 
 
