@@ -235,10 +235,13 @@ int tc_reduce_slabs(const float *slabs, float *out, int S, long n, int accumulat
 int tc_layernorm_bwd(int x_dtype, const void *x, int ldx, const float *gamma, const float *dy, float *dx,
                      int accumulate, float *dgamma, float *dbeta, int M, int E, float eps, void *stream);
 /* The same with the incoming gradient in either element type (bf16: what a bf16 Linear hands back
- * under autocast, transcodon/modules.py:83-105 run through pretraining.py:235) and its own row stride. */
+ * under autocast, transcodon/modules.py:83-105 run through pretraining.py:235) and its own row stride.
+ * dx_bf16 (optional, dense [M,E]) receives the final dx rounded to bf16 and dx_colsum (optional, f32
+ * [E], ACCUMULATED, needs dx_bf16) its column sums: the operand and the bias gradient of the Linear
+ * layer below, which would otherwise take a tc_colsum pass over dx. */
 int tc_layernorm_bwd_dy(int x_dtype, const void *x, int ldx, const float *gamma, int dy_dtype, const void *dy,
-                        int lddy, float *dx, int accumulate, float *dgamma, float *dbeta, int M, int E, float eps,
-                        void *stream);
+                        int lddy, float *dx, int accumulate, float *dgamma, float *dbeta, void *dx_bf16,
+                        float *dx_colsum, int M, int E, float eps, void *stream);
 
 /* out = dy * gelu'(u), elementwise over n values (exact erf form); u and out have type dtype. */
 int tc_dgelu(int dtype, const float *dy, const void *u, void *out, long n, void *stream);

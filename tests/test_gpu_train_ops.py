@@ -101,6 +101,15 @@ def test_layernorm_backward(xdtype, dydtype, E):
     np.testing.assert_allclose(dbet.cpu().numpy(), bb.grad.numpy(), rtol=1e-3, atol=2e-3)
     dx2 = ops.layernorm_bwd(x.to(DEV, xdtype), g.to(DEV), dy.to(DEV, dydtype), dgam, dbet)
     np.testing.assert_allclose(dx2.cpu().numpy(), xx.grad.numpy(), rtol=1e-4, atol=1e-4)
+    # fused outputs for the Linear layer below: bf16 copy of the final dx and its column sums (accumulated)
+    copy = torch.zeros(M, E, dtype=torch.bfloat16, device=DEV)
+    csum = torch.ones(E, device=DEV)
+    dx3 = carry.to(DEV).clone()
+    ops.layernorm_bwd(x.to(DEV, xdtype), g.to(DEV), dy.to(DEV, dydtype), dgam, dbet, dx=dx3, accumulate=True,
+                      dx_bf16=copy, dx_colsum=csum)
+    assert torch.equal(dx3, dx)
+    assert torch.equal(copy, dx3.to(torch.bfloat16))
+    np.testing.assert_allclose(csum.cpu().numpy(), 1.0 + dx3.double().sum(0).cpu().numpy(), rtol=1e-4, atol=2e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

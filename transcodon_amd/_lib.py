@@ -84,8 +84,8 @@ _SIGNATURES = {
     "tc_reduce_slabs": (C.c_int, [vp, vp, C.c_int, C.c_long, C.c_int, vp]),
     "tc_layernorm_bwd": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int,
                                    C.c_float, vp]),
-    "tc_layernorm_bwd_dy": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int,
-                                      C.c_int, C.c_float, vp]),
+    "tc_layernorm_bwd_dy": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp,
+                                      C.c_int, C.c_int, C.c_float, vp]),
     "tc_dgelu": (C.c_int, [C.c_int, vp, vp, vp, C.c_long, vp]),
     "tc_head_logits_bwd": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
                                      C.c_int, C.c_int, C.c_int, C.c_float, vp]),

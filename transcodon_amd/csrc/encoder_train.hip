@@ -140,7 +140,7 @@ int check_desc(const tc_encoder_desc *d, const char *who) {
     } while (0)
 
 // dW[n_out, n_in] += dY^T X with dY [M, n_out] (element type in_dt) and X [M, n_in] (dtype dt);
-// dbias[n_out] += column sums of dY.  dy_rowmajor (optional, dense) receives dY converted to dt.
+// dbias[n_out] += column sums of dY (bf16 mode: skipped when dbias is null).  dy_rowmajor (optional, dense) receives dY converted to dt.
 // ld_dy / ld_x: row strides of dY and X in elements.
 int linear_wgrad(const tc_encoder_desc *d, TrainWs &w, int in_dt, const void *dy, int ld_dy, void *dy_rowmajor,
                  const void *x, int ld_x, int M, int n_out, int n_in, float *dW, float *dbias, void *stream) {
@@ -158,7 +158,7 @@ int linear_wgrad(const tc_encoder_desc *d, TrainWs &w, int in_dt, const void *dy
             TC_TRY(tc_colsum(TC_F32, dy, ld_dy, dy_rowmajor, n_out, dbias, M, n_out, stream));
             dyb = dy_rowmajor;
             ld_dy = n_out;
-        } else {
+        } else if (dbias) {      // null: the producer of dY already added its column sums to the bias gradient
             TC_TRY(tc_colsum(TC_BF16, dy, ld_dy, nullptr, 0, dbias, M, n_out, stream));
         }
         TC_TRY(tc_gemm_tn(dyb, ld_dy, x, ld_x, w.slabs, n_in, M, n_out, n_in, splits, stream));
@@ -304,7 +304,13 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
     }
     TC_REQUIRE(have_dhf, "tc_encoder_backward: no output gradient");
     // final LayerNorm (input: the forward's last residual state, still in w.x)
-    TC_TRY(tc_layernorm_bwd(TC_F32, w.x, E, d->lnf_g, w.t0, dx, 0, g->lnf_g, g->lnf_b, M, E, d->ln_eps, stream));
+    // bf16 mode: every LayerNorm backward also leaves the bf16 copy of the residual-stream gradient it
+    // has just completed (w.dyb) and adds its column sums to the bias gradient of the Linear layer below
+    // (fc2 of the layer underneath, or this layer's out-proj), which saves a pass over dx per Linear.
+    const bool fuse = dt == TC_BF16;
+    TC_TRY(tc_layernorm_bwd_dy(TC_F32, w.x, E, d->lnf_g, TC_F32, w.t0, E, dx, 0, g->lnf_g, g->lnf_b,
+                               fuse ? w.dyb : nullptr, fuse ? g->layers[d->num_layers - 1].b_fc2 : nullptr, M, E,
+                               d->ln_eps, stream));
 
     for (int l = d->num_layers - 1; l >= 0; --l) {
         const tc_layer_weights &lw = d->layers[l];
@@ -314,7 +320,10 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
                        lg.w_fc1 && lg.b_fc1 && lg.w_fc2 && lg.b_fc2,
                    "tc_encoder_backward: layer %d has a null gradient pointer", l);
         // ---- feed-forward block: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) ----
-        TC_TRY(linear_wgrad(d, w, TC_F32, dx, E, w.dyb, sv.mid, w.ld_f, M, E, F, lg.w_fc2, lg.b_fc2, stream));
+        if (fuse)
+            TC_TRY(linear_wgrad(d, w, TC_BF16, w.dyb, E, nullptr, sv.mid, w.ld_f, M, E, F, lg.w_fc2, nullptr, stream));
+        else
+            TC_TRY(linear_wgrad(d, w, TC_F32, dx, E, w.dyb, sv.mid, w.ld_f, M, E, F, lg.w_fc2, lg.b_fc2, stream));
         TC_TRY(transpose_weight(d, w, lw.w_fc2, E, F, stream));
         TC_TRY(tc_gemm_train(dt, TC_EPI_DGELU, w.dyb, E, w.wt, nullptr, sv.u, w.wide, nullptr, w.ld_f, M, F, E, 1,
                              stream));
@@ -324,10 +333,13 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
         // bf16 Linear returns under autocast), half the bytes for the product to write and the LayerNorm to read
         TC_TRY(tc_gemm(dt, TC_EPI_BIAS, w.wide, w.ld_f, w.wt, nullptr, nullptr, w.t0, E, M, E, F, 0.f, nullptr, nullptr, 0,
                        0, stream));
-        TC_TRY(tc_layernorm_bwd_dy(TC_F32, sv.x_mid, E, lw.ln2_g, dt, w.t0, E, dx, 1, lg.ln2_g, lg.ln2_b, M, E,
-                                   d->ln_eps, stream));
+        TC_TRY(tc_layernorm_bwd_dy(TC_F32, sv.x_mid, E, lw.ln2_g, dt, w.t0, E, dx, 1, lg.ln2_g, lg.ln2_b,
+                                   fuse ? w.dyb : nullptr, fuse ? lg.b_o : nullptr, M, E, d->ln_eps, stream));
         // ---- attention block: x_mid = x_in + out_proj(attn(rope(qkv(LN1(x_in))))) ----
-        TC_TRY(linear_wgrad(d, w, TC_F32, dx, E, w.dyb, sv.ao, E, M, E, E, lg.w_o, lg.b_o, stream));
+        if (fuse)
+            TC_TRY(linear_wgrad(d, w, TC_BF16, w.dyb, E, nullptr, sv.ao, E, M, E, E, lg.w_o, nullptr, stream));
+        else
+            TC_TRY(linear_wgrad(d, w, TC_F32, dx, E, w.dyb, sv.ao, E, M, E, E, lg.w_o, lg.b_o, stream));
         TC_TRY(transpose_weight(d, w, lw.w_o, E, E, stream));
         void *d_ao = w.tr_b;      // free between weight-gradient products
         TC_TRY(tc_gemm(dt, TC_EPI_BIAS, w.dyb, E, w.wt, nullptr, nullptr, d_ao, E, M, E, E, 0.f, nullptr, nullptr, 0, 0,
@@ -338,7 +350,9 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
         TC_TRY(transpose_weight(d, w, lw.w_qkv, 3 * E, E, stream));
         TC_TRY(tc_gemm(dt, TC_EPI_BIAS, w.wide, 3 * E, w.wt, nullptr, nullptr, w.t0, E, M, E, 3 * E, 0.f, nullptr, nullptr,
                        0, 0, stream));
-        TC_TRY(tc_layernorm_bwd_dy(TC_F32, sv.x_in, E, lw.ln1_g, dt, w.t0, E, dx, 1, lg.ln1_g, lg.ln1_b, M, E,
+        const bool below = fuse && l > 0;    // layer 0 hands dx to the embedding backward only
+        TC_TRY(tc_layernorm_bwd_dy(TC_F32, sv.x_in, E, lw.ln1_g, dt, w.t0, E, dx, 1, lg.ln1_g, lg.ln1_b,
+                                   below ? w.dyb : nullptr, below ? g->layers[l - 1].b_fc2 : nullptr, M, E,
                                    d->ln_eps, stream));
         if (ready) ready(l, user);       // every kernel that writes layer l's gradients is enqueued
     }

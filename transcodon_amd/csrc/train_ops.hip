@@ -80,19 +80,22 @@ __global__ __launch_bounds__(64 * kLnbWaves) void layernorm_bwd_kernel(const TX 
                                                             const TDY *__restrict__ dy, long lddy,
                                                             float *__restrict__ dx, int accumulate,
                                                             float *__restrict__ dgamma,
-                                                            float *__restrict__ dbeta, int M, int E,
+                                                            float *__restrict__ dbeta,
+                                                            uint16_t *__restrict__ dx_bf16,
+                                                            float *__restrict__ dx_colsum, int M, int E,
                                                             float eps) {
-    __shared__ float red[2][NCH * 256];
+    __shared__ float red[3][NCH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 2 * NCH * 256; i += 64 * kLnbWaves) (&red[0][0])[i] = 0.f;
+    for (int i = threadIdx.x; i < 3 * NCH * 256; i += 64 * kLnbWaves) (&red[0][0])[i] = 0.f;
     __syncthreads();
-    f32x4 g_[NCH], dg[NCH], db[NCH];
+    f32x4 g_[NCH], dg[NCH], db[NCH], dc[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int col = c * 256 + lane * 4;
         g_[c] = col < E ? *reinterpret_cast<const f32x4 *>(gamma + col) : f32x4{0, 0, 0, 0};
         dg[c] = f32x4{0, 0, 0, 0};
         db[c] = f32x4{0, 0, 0, 0};
+        dc[c] = f32x4{0, 0, 0, 0};
     }
     for (int row = blockIdx.x * kLnbWaves + wave; row < M; row += gridDim.x * kLnbWaves) {
         f32x4 xv[NCH], dyv[NCH];
@@ -164,6 +167,13 @@ __global__ __launch_bounds__(64 * kLnbWaves) void layernorm_bwd_kernel(const TX 
                 float *po = dx + (long)row * E + col;
                 if (accumulate) o += *reinterpret_cast<const f32x4 *>(po);
                 *reinterpret_cast<f32x4 *>(po) = o;
+                if (dx_bf16) {       // what the next Linear's gradients read: bf16 copy + column sums of dx
+                    u32x2 w;
+                    w[0] = tc_pack_bf16(o[0], o[1]);
+                    w[1] = tc_pack_bf16(o[2], o[3]);
+                    *reinterpret_cast<u32x2 *>(dx_bf16 + (long)row * E + col) = w;
+                    dc[c] += o;
+                }
             }
         }
     }
@@ -174,11 +184,13 @@ __global__ __launch_bounds__(64 * kLnbWaves) void layernorm_bwd_kernel(const TX 
         for (int j = 0; j < 4; ++j) {
             atomicAdd(&red[0][c * 256 + lane * 4 + j], dg[c][j]);
             atomicAdd(&red[1][c * 256 + lane * 4 + j], db[c][j]);
+            if (dx_colsum) atomicAdd(&red[2][c * 256 + lane * 4 + j], dc[c][j]);
         }
     __syncthreads();
     for (int col = threadIdx.x; col < E; col += 64 * kLnbWaves) {
         atomicAdd(dgamma + col, red[0][col]);
         atomicAdd(dbeta + col, red[1][col]);
+        if (dx_colsum) atomicAdd(dx_colsum + col, red[2][col]);
     }
 }
 
@@ -483,7 +495,7 @@ extern "C" int tc_reduce_slabs(const float *slabs, float *out, int S, long n, in
 
 extern "C" int tc_layernorm_bwd_dy(int x_dtype, const void *x, int ldx, const float *gamma, int dy_dtype,
                                    const void *dy, int lddy, float *dx, int accumulate, float *dgamma, float *dbeta,
-                                   int M, int E, float eps, void *stream) {
+                                   void *dx_bf16, float *dx_colsum, int M, int E, float eps, void *stream) {
     TC_REQUIRE(x && gamma && dy && dx && dgamma && dbeta, "tc_layernorm_bwd: null operand");
     TC_REQUIRE(M > 0 && E > 0 && E % 4 == 0 && E <= 1024 && ldx >= E && lddy >= E,
                "tc_layernorm_bwd: bad shape M=%d E=%d", M, E);
@@ -492,6 +504,8 @@ extern "C" int tc_layernorm_bwd_dy(int x_dtype, const void *x, int ldx, const fl
     TC_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && ((uintptr_t)x % (x_dtype == TC_F32 ? 16 : 8)) == 0 &&
                    ((uintptr_t)dy % (dy_dtype == TC_F32 ? 16 : 8)) == 0 && tc_aligned16(dx),
                "tc_layernorm_bwd: x and dy rows must be 4-element aligned, dx 16-byte aligned");
+    TC_REQUIRE((dx_colsum == nullptr || dx_bf16 != nullptr) && ((uintptr_t)dx_bf16 & 7u) == 0,
+               "tc_layernorm_bwd: the column sums come with the bf16 copy (8-byte aligned)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // Waves in flight, not workgroup shape, set the pace (M = 65536, E = 768, accumulating; the same
     // totals as 4-, 8- or 16-wave workgroups give the same times): 2048 waves 169 us with f32 dy and
@@ -503,7 +517,8 @@ extern "C" int tc_layernorm_bwd_dy(int x_dtype, const void *x, int ldx, const fl
     const int nch = (E + 255) / 256;
 #define TC_LNB(TX, TDY, N)                                                                                      \
     TC_LAUNCH((layernorm_bwd_kernel<TX, TDY, N>), dim3(blocks), dim3(64 * kLnbWaves), 0, s, static_cast<const TX *>(x), \
-              (long)ldx, gamma, static_cast<const TDY *>(dy), (long)lddy, dx, accumulate, dgamma, dbeta, M, E, eps)
+              (long)ldx, gamma, static_cast<const TDY *>(dy), (long)lddy, dx, accumulate, dgamma, dbeta,           \
+              static_cast<uint16_t *>(dx_bf16), dx_colsum, M, E, eps)
 #define TC_LNB_N(TX, TDY)                                                                          \
     switch (nch) { case 1: TC_LNB(TX, TDY, 1); break; case 2: TC_LNB(TX, TDY, 2); break;           \
                    case 3: TC_LNB(TX, TDY, 3); break; default: TC_LNB(TX, TDY, 4); break; }
@@ -521,7 +536,8 @@ extern "C" int tc_layernorm_bwd_dy(int x_dtype, const void *x, int ldx, const fl
 extern "C" int tc_layernorm_bwd(int x_dtype, const void *x, int ldx, const float *gamma, const float *dy,
                                 float *dx, int accumulate, float *dgamma, float *dbeta, int M, int E, float eps,
                                 void *stream) {
-    return tc_layernorm_bwd_dy(x_dtype, x, ldx, gamma, TC_F32, dy, E, dx, accumulate, dgamma, dbeta, M, E, eps, stream);
+    return tc_layernorm_bwd_dy(x_dtype, x, ldx, gamma, TC_F32, dy, E, dx, accumulate, dgamma, dbeta, nullptr, nullptr, M,
+                               E, eps, stream);
 }
 
 extern "C" int tc_dgelu(int dtype, const float *dy, const void *u, void *out, long n, void *stream) {

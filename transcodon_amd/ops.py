@@ -206,9 +206,10 @@ def reduce_slabs(slabs, out=None, accumulate=False):
     return out
 
 
-def layernorm_bwd(x, gamma, dy, dgamma, dbeta, dx=None, accumulate=False, eps=1e-5):
-    """x and dy may be column slices of wider buffers (row stride = leading dimension); dy f32 or bf16."""
-    _dev(gamma, dy, dgamma, dbeta, dx)
+def layernorm_bwd(x, gamma, dy, dgamma, dbeta, dx=None, accumulate=False, eps=1e-5, dx_bf16=None, dx_colsum=None):
+    """x and dy may be column slices of wider buffers (row stride = leading dimension); dy f32 or bf16.
+    dx_bf16 [M,E] bf16 / dx_colsum [E] f32 (accumulated): optional bf16 copy and column sums of the final dx."""
+    _dev(gamma, dy, dgamma, dbeta, dx, dx_bf16, dx_colsum)
     if not x.is_cuda or x.stride(1) != 1 or dy.stride(1) != 1:
         raise ValueError("x must be a GPU tensor, x and dy with unit column stride")
     M, E = dy.shape
@@ -216,7 +217,8 @@ def layernorm_bwd(x, gamma, dy, dgamma, dbeta, dx=None, accumulate=False, eps=1e
         dx = torch.empty(M, E, dtype=torch.float32, device=dy.device)
         accumulate = False
     check(_lib.load().tc_layernorm_bwd_dy(_dt(x), _p(x), x.stride(0), _p(gamma), _dt(dy), _p(dy), dy.stride(0), _p(dx),
-                                          int(accumulate), _p(dgamma), _p(dbeta), M, E, eps, _stream()),
+                                          int(accumulate), _p(dgamma), _p(dbeta), _p(dx_bf16), _p(dx_colsum), M, E, eps,
+                                          _stream()),
           "tc_layernorm_bwd")
     return dx
 
