@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Step time of the 256x512 forward + decode with and without the in-library launch timers
-(tc_prof_enable brackets every launch with two HIP events)."""
+"""Step time of the forward + decode with and without the in-library launch timers.
+
+    python tools/prof_overhead.py [B T]        (default 256 512, the bench workload)
+"""
 import os
 import sys
 import time
@@ -13,7 +15,7 @@ import transcodon_amd as ta  # noqa: E402
 from transcodon_amd import _lib, ops  # noqa: E402
 
 dev = torch.device("cuda", 0)
-B, T = bench.B_PER_GPU, bench.SEQ_LEN
+B, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (bench.B_PER_GPU, bench.SEQ_LEN)
 model = ta.ProteinBertModel(ta.default_args(), ta.Alphabet.from_architecture("CodonModel"))
 ta.init_weights(model, seed=1234)
 model = model.to(dev).eval().set_compute_dtype(torch.bfloat16)
@@ -44,4 +46,4 @@ for rnd in range(3):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 100
         lib.tc_prof_enable(0)
-        print(f"launch timers {'on ' if on else 'off'}: {ms:.3f} ms/step", flush=True)
+        print(f"{B}x{T} launch timers {'on ' if on else 'off'}: {ms:.3f} ms/step  {B * T / ms / 1e3:.3f} M tokens/s", flush=True)
