@@ -175,6 +175,92 @@ __global__ __launch_bounds__(256) void head_kernel(const T *__restrict__ g, int 
     if (lane < V) out[(long)row * V + lane] = mine;
 }
 
+// The same head for the two class counts of the model (V = 10 bases / specials, V = 3 structure
+// labels) with this lane's slice of W held in registers: the generic kernel re-reads the whole W
+// (30 KB at V = 10) through the L1 for every row, which bounds it at about 1 TB/s of input.  A wave
+// keeps 4 V NCH weights and walks rows with a grid stride; arithmetic and reduction order are those
+// of the generic kernel, so the results are identical.  What is left is the chain of V + 2 wave
+// reductions per row (a joint halving exchange of the V sums compiled to worse code and ran slower).
+template <typename T, int NCH, int V>
+__global__ __launch_bounds__(256) void head_rows_kernel(const T *__restrict__ g, int ldg, int col0,
+                                                        const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta,
+                                                        const float *__restrict__ W,
+                                                        const float *__restrict__ bias,
+                                                        float *__restrict__ out, int M, int E, float eps) {
+    const int lane = threadIdx.x & 63;
+    f32x4 wreg[V][NCH], gm[NCH], bt[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        const bool ok = col < E;
+        gm[c] = ok ? *reinterpret_cast<const f32x4 *>(gamma + col) : f32x4{0, 0, 0, 0};
+        bt[c] = ok ? *reinterpret_cast<const f32x4 *>(beta + col) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int o = 0; o < V; ++o)
+            wreg[o][c] = ok ? *reinterpret_cast<const f32x4 *>(W + (long)o * E + col) : f32x4{0, 0, 0, 0};
+    }
+    const float my_bias = lane < V ? bias[lane] : 0.f;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+        const T *src = g + (long)row * ldg + col0;
+        f32x4 v[NCH];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < E) {
+                if constexpr (sizeof(T) == 2) {
+                    const u32x2 w = *reinterpret_cast<const u32x2 *>(src + col);
+                    v[c] = f32x4{tc_bf16_lo(w[0]), tc_bf16_hi(w[0]), tc_bf16_lo(w[1]), tc_bf16_hi(w[1])};
+                } else {
+                    v[c] = *reinterpret_cast<const f32x4 *>(src + col);
+                }
+            } else {
+                v[c] = f32x4{0, 0, 0, 0};
+            }
+            s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        }
+        const float mean = tc_wave_sum(s) / (float)E;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < E) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[c][j] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        const float rstd = rsqrtf(tc_wave_sum(q) / (float)E + eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < E) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[c][j] = (v[c][j] - mean) * rstd * gm[c][j] + bt[c][j];
+            }
+        }
+        float mine = 0.f;                           // lane o keeps logit o
+#pragma unroll
+        for (int o = 0; o < V; ++o) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int col = c * 256 + lane * 4;
+                if (col < E) {
+                    const f32x4 wv = wreg[o][c];
+                    d += v[c][0] * wv[0] + v[c][1] * wv[1] + v[c][2] * wv[2] + v[c][3] * wv[3];
+                }
+            }
+            d = tc_wave_sum(d);
+            if (lane == o) mine = d + my_bias;
+        }
+        if (lane < V) out[(long)row * V + lane] = mine;
+    }
+}
+
 // ---- greedy synonymous-codon decode ----------------------------------------------------------
 // Amino-acid code = index into "FLIMVPTAY_HQNKDECWRSG"; codons in the table order of the
 // reference; bases coded 0..3 = A,U,C,G (logit columns 5..8).
@@ -405,6 +491,18 @@ extern "C" int tc_head_logits_fwd(int dtype, const void *g, int ldg, int col0, c
     TcProfScope prof(TC_PROF_HEAD, s, (double)M * (E * (double)esz + 4.0 * V));
     const dim3 grid((M + 3) / 4), block(256);
     const int nch = (E + 255) / 256;
+    if (nch == 3 && (V == 10 || V == 3)) {
+        // the model's own heads: weights in registers, rows by grid stride (1024 workgroups: 4 per CU)
+        const dim3 rgrid((M + 3) / 4 < 1024 ? (M + 3) / 4 : 1024);
+#define TC_HEAD_ROWS(TY, VV)                                                                              \
+    TC_LAUNCH((head_rows_kernel<TY, 3, VV>), rgrid, block, 0, s, static_cast<const TY *>(g), ldg, col0, \
+              gamma, beta, W, bias, out, M, E, eps)
+        if (dtype == TC_BF16) { if (V == 10) TC_HEAD_ROWS(uint16_t, 10); else TC_HEAD_ROWS(uint16_t, 3); }
+        else { if (V == 10) TC_HEAD_ROWS(float, 10); else TC_HEAD_ROWS(float, 3); }
+#undef TC_HEAD_ROWS
+        TC_CHECK_LAUNCH("tc_head_logits_fwd");
+        return TC_OK;
+    }
 #define TC_HEAD(TY, N)                                                                          \
     TC_LAUNCH((head_kernel<TY, N>), grid, block, 0, s, static_cast<const TY *>(g), ldg, \
                        col0, gamma, beta, W, bias, out, M, E, V, eps)
