@@ -107,6 +107,8 @@ int tc_gemm(int dtype, int epilogue, const void *A, int lda, const void *W, cons
  * GEMM variants needed by the training step (pretraining.py:94-134 forward + autograd backward):
  *   TC_EPI_BIAS_GELU_SAVE  forward fc1: also keeps the pre-activation (out2, element type dtype);
  *   TC_EPI_DGELU           data gradient through fc1's GELU: aux = saved pre-activation [M,N];
+ *                          out2 (optional, f32 [N]) += column sums of the result, i.e. fc1's bias
+ *                          gradient (accumulated with float atomics: the last bits vary run to run);
  *   TC_EPI_PLAIN_F32       data / weight gradients with f32 output.  With splits > 1 the k range
  *                          is cut into `splits` parts and part s writes its partial product to
  *                          out + s*M*ldo (f32); tc_reduce_slabs adds the parts up.

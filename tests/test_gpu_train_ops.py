@@ -73,6 +73,13 @@ def test_gelu_save_and_dgelu_epilogues(dtype):
         uu = pre_f.clone().requires_grad_(True)
         (O.gelu(uu) * (dz @ w2)).sum().backward()
     np.testing.assert_allclose(du.float().cpu().numpy(), uu.grad.numpy(), **tol)
+    # the same call can add the column sums of its result (the bias gradient of the layer below) to out2
+    csum = torch.full((N,), 0.5, device=DEV)
+    du_b = ops.gemm_train(dz.to(DEV, dtype), w2t, _lib.EPI_DGELU, aux=pre, out2=csum)
+    assert torch.equal(du_b, du)
+    want = 0.5 + uu.grad.double().sum(0).numpy()
+    np.testing.assert_allclose(csum.cpu().numpy(), want, rtol=2e-2 if dtype == torch.bfloat16 else 1e-4,
+                               atol=0.02 * float(np.abs(want).max()) if dtype == torch.bfloat16 else 1e-2)
     # standalone elementwise form
     du2 = ops.dgelu((dz @ w2).to(DEV), pre)
     np.testing.assert_allclose(du2.float().cpu().numpy(), uu.grad.numpy(), **tol)

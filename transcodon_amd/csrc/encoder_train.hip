@@ -325,9 +325,11 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
         else
             TC_TRY(linear_wgrad(d, w, TC_F32, dx, E, w.dyb, sv.mid, w.ld_f, M, E, F, lg.w_fc2, lg.b_fc2, stream));
         TC_TRY(transpose_weight(d, w, lw.w_fc2, E, F, stream));
-        TC_TRY(tc_gemm_train(dt, TC_EPI_DGELU, w.dyb, E, w.wt, nullptr, sv.u, w.wide, nullptr, w.ld_f, M, F, E, 1,
-                             stream));
-        TC_TRY(linear_wgrad(d, w, dt, w.wide, w.ld_f, nullptr, sv.h2, E, M, F, E, lg.w_fc1, lg.b_fc1, stream));
+        // fc1's bias gradient is summed in the epilogue that produces d_u (bf16 mode)
+        TC_TRY(tc_gemm_train(dt, TC_EPI_DGELU, w.dyb, E, w.wt, nullptr, sv.u, w.wide, fuse ? lg.b_fc1 : nullptr, w.ld_f, M,
+                             F, E, 1, stream));
+        TC_TRY(linear_wgrad(d, w, dt, w.wide, w.ld_f, nullptr, sv.h2, E, M, F, E, lg.w_fc1, fuse ? nullptr : lg.b_fc1,
+                            stream));
         TC_TRY(transpose_weight(d, w, lw.w_fc1, F, E, stream));
         // the gradient handed to a LayerNorm comes out of the product in the compute type (bf16: what a
         // bf16 Linear returns under autocast), half the bytes for the product to write and the LayerNorm to read

@@ -39,6 +39,7 @@ struct GemmParams {
     const float *rope_sin;
     const char *aux;       // TC_EPI_DGELU: pre-activation u, element type T, leading dimension ldo
     char *out2;            // TC_EPI_BIAS_GELU_SAVE: pre-activation output, element type T
+    float *colsum;         // TC_EPI_DGELU, large tiles: column sums of the result are added here (f32 [N])
     long lda_bytes, ldw_bytes;
     long slab_elems;       // split-K: f32 elements between the partial outputs of two splits
     int splits;            // split-K factor of the small-tile kernel (1 = off)
@@ -502,10 +503,17 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
         }
     }
     if constexpr (EPI == TC_EPI_DGELU) {
+        // Column sums of the result (the bias gradient of the layer whose output gradient this is)
+        // are taken on the way: rows in registers first, then the 16 lanes that hold the 16 rows of
+        // a block, one atomic per column and wave.
+        f32x4 csum[NI1 - NI0];
+#pragma unroll
+        for (int ni = NI0; ni < NI1; ++ni) csum[ni - NI0] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mi = MI0; mi < MI1; ++mi) {
             const int m = mrow0 + mi_off<LAY>(mi);
             const char *up = p.aux + ((long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0) * 2;
+            const float live = m < p.M ? 1.0f : 0.0f;
 #pragma unroll
             for (int ni = NI0; ni < NI1; ++ni) {
                 const u32x2 w = *reinterpret_cast<const u32x2 *>(up + ni_off<LAY>(ni) * 2);
@@ -515,6 +523,22 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
                 v[2] *= gelu_grad<true>(tc_bf16_lo(w[1]));
                 v[3] *= gelu_grad<true>(tc_bf16_hi(w[1]));
                 acc[ni][mi] = v;
+                csum[ni - NI0] += v * live;
+            }
+        }
+        if (p.colsum) {
+#pragma unroll
+            for (int ni = NI0; ni < NI1; ++ni) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // inclusive scan over the 16 lanes of a row by DPP shifts (VALU only): lane 15 ends with the sum
+                    float t = csum[ni - NI0][e];
+                    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x111, 0xf, 0xf, true));
+                    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x112, 0xf, 0xf, true));
+                    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x114, 0xf, 0xf, true));
+                    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x118, 0xf, 0xf, true));
+                    if (frow == 15) atomicAdd(p.colsum + ncol0 + ni_off<LAY>(ni) + e, t);
+                }
             }
         }
     }
@@ -1491,8 +1515,19 @@ static int gemm_impl(int dtype, int epilogue, const void *A, int lda, const void
         if (force == 128) big = false;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    TcProfScope prof(TC_PROF_GEMM, s, 2.0 * (double)M * (double)N * (double)K);
-    return dtype == TC_BF16 ? dispatch<__bf16>(epilogue, p, big, s) : dispatch<float>(epilogue, p, big, s);
+    // DGELU: out2 (optional, f32 [N]) receives += column sums of the result.  The large tile adds
+    // them in its epilogue; the other kernels are followed by a pass over the result.
+    const bool want_colsum = epilogue == TC_EPI_DGELU && out2 != nullptr;
+    if (epilogue == TC_EPI_DGELU) p.out2 = nullptr;
+    p.colsum = want_colsum && big ? static_cast<float *>(out2) : nullptr;
+    int rc;
+    {
+        TcProfScope prof(TC_PROF_GEMM, s, 2.0 * (double)M * (double)N * (double)K);
+        rc = dtype == TC_BF16 ? dispatch<__bf16>(epilogue, p, big, s) : dispatch<float>(epilogue, p, big, s);
+    }
+    if (rc == TC_OK && want_colsum && !big)
+        rc = tc_colsum(dtype, out, ldo, nullptr, 0, static_cast<float *>(out2), M, N, stream);
+    return rc;
 }
 
 extern "C" int tc_gemm(int dtype, int epilogue, const void *A, int lda, const void *W, const float *bias,

@@ -162,7 +162,8 @@ def ce_loss(logits2d, labels, want_grad=False, grad_scale=1.0):
 # ---- training-step kernels -----------------------------------------------------------------
 def gemm_train(a, w, epilogue, bias=None, aux=None, out=None, out2=None, splits=1):
     """tc_gemm_train: EPI_PLAIN_F32 (f32 out, optional split-K slabs [splits, M, N]),
-    EPI_BIAS_GELU_SAVE (returns (gelu, pre)), EPI_DGELU (aux = pre-activation)."""
+    EPI_BIAS_GELU_SAVE (returns (gelu, pre)), EPI_DGELU (aux = pre-activation; out2: optional f32 [N]
+    that receives += column sums of the result)."""
     _dev(a, w, bias, aux, out, out2)
     M, K = a.shape
     N = w.shape[0]
