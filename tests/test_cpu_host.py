@@ -116,19 +116,33 @@ def _tiny_model(seed=3):
 
 @pytest.mark.parametrize("ext", [".safetensors", ".ckpt"])
 def test_checkpoint_round_trip_with_reference_prefix(tmp_path, ext):
-    """Files carry the 'model.' prefix of the reference's CodonModel wrapper (infer.py:248-250);
-    the tied lm_head.weight is restored when safetensors left the alias out."""
+    """Files carry the 'model.' prefix of the reference's CodonModel wrapper and every key of its
+    state_dict, the tied lm_head.weight included (infer.py:248-250 loads with strict=True)."""
     from transcodon_amd import checkpoint
     a, b = _tiny_model(3), _tiny_model(4)
     path = str(tmp_path / ("w" + ext))
     checkpoint.save(a, path, step=7)
     raw = checkpoint.read_state_dict(path)
-    assert all(k.startswith("model.") for k in raw)
-    assert ("model.lm_head.weight" in raw) == (ext == ".ckpt")
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")))
+    want = {"model." + k for k in ref if not k.startswith("layers.") or k.split(".")[1] in ("0", "1")}
+    assert set(raw) == want
+    assert torch.equal(raw["model.lm_head.weight"], raw["model.embed_tokens.weight"])
     checkpoint.load_into(b, path)
     for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
         assert torch.equal(v, w), k
     assert b.lm_head.weight is b.embed_tokens.weight
+
+
+def test_checkpoint_without_tied_alias(tmp_path):
+    """A safetensors file whose writer dropped the tied alias still loads."""
+    from safetensors.torch import save_file
+    from transcodon_amd import checkpoint
+    a, b = _tiny_model(3), _tiny_model(4)
+    sd = {"model." + k: v.detach().clone() for k, v in a.state_dict().items() if k != "lm_head.weight"}
+    path = str(tmp_path / "noalias.safetensors")
+    save_file(sd, path)
+    checkpoint.load_into(b, path)
+    assert torch.equal(a.embed_tokens.weight, b.lm_head.weight)
 
 
 def test_checkpoint_without_prefix_and_bad_file(tmp_path):

@@ -345,3 +345,40 @@ def test_gradient_sync_callback_path_single_rank():
         np.testing.assert_allclose(fb.grad.cpu().numpy(), 2 * fa.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+def test_store_backed_model_sees_weights_written_through_parameters(tmp_path):
+    """Weights written THROUGH the re-homed parameters (load_state_dict, checkpoint.load_into, an
+    in-place copy) bump the parameters' version counters, not the flat buffer's: the bf16 weight
+    shadow and the packed descriptor must still be refreshed."""
+    from transcodon_amd import checkpoint
+    cfg = O.TINY
+    sd_a, sd_b = seeded_state_dict(cfg, 51, perturb=True), seeded_state_dict(cfg, 52, perturb=True)
+    tok, sp, _, _ = _batch(cfg, 2, 40, 3, pad_tail=(0, 9))
+    for dtype in (torch.bfloat16, torch.float32):
+        m = _model(cfg, sd_a, dtype)
+        TR.FlatParameters(m)
+        want_b = _model(cfg, sd_b, dtype)
+        with torch.no_grad():
+            first = m(tok.to(DEV), sp.to(DEV))
+            m.load_state_dict(sd_b)
+            got = m(tok.to(DEV), sp.to(DEV))
+            ref = want_b(tok.to(DEV), sp.to(DEV))
+        assert not torch.equal(first["logits"], got["logits"])
+        for k in ("logits", "struct_label_output"):
+            np.testing.assert_array_equal(got[k].cpu().numpy(), ref[k].cpu().numpy())
+        # and back again through a checkpoint file and an in-place parameter write
+        path = str(tmp_path / f"a_{dtype}.safetensors".replace("torch.", ""))
+        checkpoint.save(_model(cfg, sd_a, dtype), path)
+        checkpoint.load_into(m, path)
+        with torch.no_grad():
+            again = m(tok.to(DEV), sp.to(DEV))
+            np.testing.assert_array_equal(again["logits"].cpu().numpy(), first["logits"].cpu().numpy())
+            m.structure_linear.bias.add_(1.0)           # enters the structure logits as a plain sum
+            shifted = m(tok.to(DEV), sp.to(DEV))
+            m.layers[0].fc1.weight.mul_(0.5)
+            moved = m(tok.to(DEV), sp.to(DEV))
+        np.testing.assert_array_equal(shifted["logits"].cpu().numpy(), again["logits"].cpu().numpy())
+        np.testing.assert_allclose((shifted["struct_label_output"] - again["struct_label_output"]).cpu().numpy(),
+                                   1.0, atol=1e-4)
+        assert not torch.equal(moved["logits"], again["logits"])

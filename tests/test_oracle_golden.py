@@ -104,10 +104,48 @@ def test_full_padded_batch(golden_dir):
 
 
 def test_schedule(golden_dir):
+    """schedule.json holds values of the lambda that the reference's CodonModel.configure_optimizers
+    hands to LambdaLR (pretraining.py:76-82), evaluated by tools/gen_golden.py on the imported
+    reference module; oracle and product restatements must reproduce them."""
+    import transcodon_amd as ta
+    from transcodon_amd import train as TR
     g = json.load(open(os.path.join(golden_dir, "schedule.json")))
-    vals = [O.warmup_cosine(s, g["warmup"], g["num_steps"]) for s in range(0, 120, 7)]
-    assert vals == g["values"]
+    for s, want in zip(g["steps"], g["values"]):
+        assert O.warmup_cosine(s, g["warmup"], g["num_steps"]) == pytest.approx(want, rel=1e-12, abs=1e-15)
+        assert TR.warmup_cosine(s, g["warmup"], g["num_steps"]) == pytest.approx(want, rel=1e-12, abs=1e-15)
     assert O.warmup_cosine(0, 10, 100) == 0.1 and O.warmup_cosine(9, 10, 100) == 1.0
+    # the optimiser the reference builds: AdamW over every parameter in one group
+    o = g["optimizer"]
+    assert (o["class"], o["lr"], o["weight_decay"], o["betas"], o["eps"], o["n_param_groups"]) == \
+        ("AdamW", 2e-4, 0.1, [0.9, 0.999], 1e-8, 1)
+    opt = TR.AdamW.__init__.__defaults__
+    assert opt == (2e-4, (0.9, 0.999), 1e-8, 0.1)
+
+
+def test_init_weights_matches_reference_classes(golden_dir):
+    """init_weights_stats.json: per-tensor statistics of the reference's CodonModel right after its
+    init_weights (pretraining.py:46-52) at the tiny configuration.  The product's init_weights must
+    put every tensor in the same class: N(0, 0.02) draw, all zeros, all ones, or left alone."""
+    import transcodon_amd as ta
+    g = json.load(open(os.path.join(golden_dir, "init_weights_stats.json")))["tensors"]
+    cfg = O.TINY
+    args = ta.default_args(num_layers=cfg.num_layers, embed_dim=cfg.embed_dim, ffn_embed_dim=cfg.ffn_embed_dim,
+                           attention_heads=cfg.attention_heads, species_vocab_size=cfg.species_vocab_size)
+    m = ta.init_weights(ta.ProteinBertModel(args, ta.Alphabet.from_architecture("CodonModel")), seed=9)
+    sd = m.state_dict()
+    assert set(sd) == set(g)
+    for k, st in g.items():
+        v = sd[k].float()
+        assert list(v.shape) == st["shape"], k
+        assert bool((v == 0).all()) == st["all_zero"], k
+        assert bool((v == 1).all()) == st["all_one"], k
+        if not st["all_zero"] and not st["all_one"] and "rope" not in k and v.numel() >= 128:
+            assert 0.015 < st["std"] < 0.025, (k, st["std"])          # the reference drew N(0, 0.02)
+            assert 0.015 < float(v.std()) < 0.025, (k, float(v.std()))
+            assert abs(float(v.mean())) < 0.01, k
+    # rope.freqs is a fixed table in both
+    np.testing.assert_allclose(sd["layers.0.self_attn.rope.freqs"].numpy(),
+                               1.0 / (10000 ** (np.arange(0, 64, 2) / 64.0)), rtol=1e-6)
 
 
 def test_oracle_autograd_matches_reference_gradients(golden_dir):

@@ -194,6 +194,7 @@ def main():
 
     rows = list(csv.DictReader(open(os.path.join(REF, "test.csv"))))
     g2 = {"rows": []}
+    all_margins = {}
     import contextlib
     import io
     for ri, row in enumerate(rows):
@@ -206,7 +207,7 @@ def main():
             aa, tmpl = aa[:2048], tmpl[: 2048 * 3]
         org = ORGANISM2ID[row["organism"]]
         rec = {"row": ri, "organism": row["organism"], "organism_id": org,
-               "protein_len": len(row["protein_seq"]), "template": tmpl}
+               "protein_len": len(row["protein_seq"]), "template": tmpl, "utr_seq": row["utr"]}
         for with_utr in (False, True):
             utr = row["utr"] if with_utr else "false"
             seq = (CodonSequence_infer(tmpl) if not with_utr
@@ -224,6 +225,7 @@ def main():
             rec[key] = {"T": len(ids), "rna": rna,
                         "min_margin": float(np.min(margins)),
                         "n_margin_lt_1e-4": int(np.sum(np.array(margins) < 1e-4))}
+            all_margins[f"r{ri}_{key}"] = np.array(margins, np.float32)
             if ri in (2, 5):
                 np.savez_compressed(
                     os.path.join(OUT, f"full_row{ri}_{key}.npz"), seed=7,
@@ -235,6 +237,8 @@ def main():
         g2["rows"].append(rec)
     with open(os.path.join(OUT, "full_testcsv_decode.json"), "w") as f:
         json.dump(g2, f, indent=1)
+    # decision margin (log p_best - log p_second) of every amino acid of every row, both modes
+    np.savez_compressed(os.path.join(OUT, "full_testcsv_margins.npz"), **all_margins)
 
     # ---- G2b: full config, padded batch of two rows (key-padding branch) ----
     r2 = O.encode(O.token_strings("false", g2["rows"][2]["template"]))
@@ -289,11 +293,50 @@ def main():
     with open(os.path.join(OUT, "decode_kat.json"), "w") as f:
         json.dump(kats, f)
 
-    # ---- G5: training objective pieces computed by torch as the reference does ----
-    sched = {"warmup": 10, "num_steps": 100,
-             "values": [O.warmup_cosine(s, 10, 100) for s in range(0, 120, 7)]}
+    # ---- G5: LR schedule and weight initialisation from the reference's own pretraining.py ----
+    # (CodonModel.__init__ / init_weights :40-58, configure_optimizers :64-92), imported with the
+    # Lightning stand-ins above; LightningModule is torch.nn.Module plus two no-op methods.
+    import pytorch_lightning as pl_shim
+
+    class _LM(torch.nn.Module):
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, *a, **k):
+            pass
+
+    pl_shim.LightningModule = _LM
+    pl_shim.Callback = object
+    spec = importlib.util.spec_from_file_location("ref_pretraining", os.path.join(REF, "pretraining.py"))
+    pre = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pre)
+    targs = argparse.Namespace(
+        num_layers=O.TINY.num_layers, embed_dim=O.TINY.embed_dim, attention_dropout=0.0, logit_bias=False,
+        rope_embedding=True, ffn_embed_dim=O.TINY.ffn_embed_dim, attention_heads=O.TINY.attention_heads,
+        species_embedding=True, struct_label=True, species_vocab_size=O.TINY.species_vocab_size,
+        max_positions=2048, learning_rate=2e-4, weight_decay=0.1, lr_scheduler="warmup_cosine",
+        warmup_steps=10, num_steps=100)
+    torch.manual_seed(3)
+    with torch.enable_grad():
+        cm = pre.CodonModel(targs, Alphabet.from_architecture("CodonModel"))
+        (optim,), (sch,) = cm.configure_optimizers()
+    lam = sch["scheduler"].lr_lambdas[0]
+    steps = list(range(0, 120, 7)) + [9, 10, 11, 109, 110, 111, 500]
+    sched = {"warmup": 10, "num_steps": 100, "steps": steps, "values": [float(lam(s)) for s in steps],
+             "optimizer": {"class": type(optim).__name__, "lr": optim.defaults["lr"],
+                           "weight_decay": optim.defaults["weight_decay"], "betas": list(optim.defaults["betas"]),
+                           "eps": optim.defaults["eps"],
+                           "n_param_groups": len(optim.param_groups),
+                           "n_params": sum(p.numel() for g in optim.param_groups for p in g["params"])}}
     with open(os.path.join(OUT, "schedule.json"), "w") as f:
         json.dump(sched, f)
+    init = {}
+    for k, v in cm.model.state_dict().items():
+        v = v.float()
+        init[k] = {"shape": list(v.shape), "mean": float(v.mean()), "std": float(v.std()) if v.numel() > 1 else 0.0,
+                   "all_zero": bool((v == 0).all()), "all_one": bool((v == 1).all())}
+    with open(os.path.join(OUT, "init_weights_stats.json"), "w") as f:
+        json.dump({"seed": 3, "config": "tiny", "tensors": init}, f, indent=0)
     print("wrote fixtures to", OUT)
 
 

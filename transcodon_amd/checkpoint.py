@@ -40,19 +40,23 @@ def load_into(model, path: str, strict: bool = True):
     sd = strip_prefix(read_state_dict(path))
     if "lm_head.weight" not in sd and "embed_tokens.weight" in sd:
         sd = dict(sd)
-        sd["lm_head.weight"] = sd["embed_tokens.weight"]      # tied (model.py:164-168); safetensors drops aliases
-    return model.load_state_dict(sd, strict=strict)
+        sd["lm_head.weight"] = sd["embed_tokens.weight"]      # tied (model.py:164-168); some writers drop aliases
+    res = model.load_state_dict(sd, strict=strict)
+    store = getattr(model, "_flat_store", None)
+    if store is not None:
+        store.mark_dirty()          # the copy went through the parameters, not through the flat buffer
+    return res
 
 
 def save(model, path: str, prefix: str = PREFIX, step: int = None):
-    """Write the model the way the reference's tools read it back: safetensors (tensors only;
-    the tied ``lm_head.weight`` alias is left out, as safetensors requires) or a Lightning-style
+    """Write the model the way the reference's tools read it back: safetensors, with every key of
+    the reference's state_dict (infer.py:249-250 loads it with strict=True, so the tied
+    ``lm_head.weight`` is written as a copy of its own), or a Lightning-style
     ``{"state_dict": ..., "global_step": ...}`` torch checkpoint for any other extension."""
     sd = {prefix + k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     if path.endswith(".safetensors"):
         from safetensors.torch import save_file
-        sd.pop(prefix + "lm_head.weight", None)
-        save_file({k: v.clone() for k, v in sd.items()}, path)
+        save_file({k: v.clone() for k, v in sd.items()}, path)      # clones: no shared storage
     else:
         torch.save({"state_dict": sd, "global_step": step}, path)

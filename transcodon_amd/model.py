@@ -102,7 +102,7 @@ class ProteinBertModel(nn.Module):
         one-kernel shadow in the compute dtype): no per-tensor concatenation or cast."""
         store = self._flat_store
         rope_len = max(512, 1 << (T - 1).bit_length())
-        key = ("store", dtype, str(device), rope_len, _lib.weights_epoch[0], store.data._version)
+        key = ("store", dtype, str(device), rope_len, store.version_key())
         if self._pack.get("key") == key:
             return self._pack
         lay = store.layout

@@ -347,11 +347,22 @@ class FlatParameters:
             (o, n), (o2, _) = self.layout.hoff["st_bias"], self.layout.hoff["st_bias2"]
             self.grad[o2:o2 + n].copy_(self.grad[o:o + n])
 
+    def version_key(self):
+        """Changes whenever the stored weights may have changed: the optimiser's epoch, writes
+        through the flat buffer, and in-place writes through any re-homed parameter (``p.copy_``,
+        ``load_state_dict``, a torch optimiser): those bump the parameter's own version counter,
+        not the base buffer's."""
+        return (_lib.weights_epoch[0], self.data._version, tuple(p._version for p in self.params))
+
+    def mark_dirty(self):
+        """Call after writing weights by any route the version counters cannot see."""
+        _lib.weights_epoch[0] += 1
+
     def shadow(self, dtype):
         """``data`` in the compute dtype (itself for float32), refreshed when the weights changed."""
         if dtype == torch.float32:
             return self.data
-        key = (_lib.weights_epoch[0], self.data._version)
+        key = self.version_key()
         ent = self._shadow.get(dtype)
         if ent is None or ent[0] != key:
             buf = ent[1] if ent is not None else torch.empty_like(self.data, dtype=dtype)
