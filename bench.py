@@ -1,27 +1,40 @@
 #!/usr/bin/env python3
 """Throughput of the TransCodon forward + greedy codon decode on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4]
 
-One step = one pass of the hot path over one synthetic batch per GPU: 256 sequences x 512
-tokens (<cls> + 5'UTR + <sep> + masked CDS template + <eos>, no padding; species ids
-uniform), bf16 operands with fp32 accumulation, weights random-initialised like the
-reference's training module (no checkpoint is available offline).  The step covers the
-embedding gather, 12 encoder layers, the final LayerNorm, the LM and structure heads and
-the synonymous-codon decode kernel; inputs are resident in HBM before the clock starts.
-For N > 1 the driver launches one process per GPU; every rank runs its own batch (weak
-scaling, no data-path collective) and the slowest rank's time is used.
+One step = one pass of the hot path over one synthetic batch per GPU.
+  --config 2 (default, the headline): 256 sequences x 512 tokens per GPU (<cls> + 5'UTR + <sep> +
+      masked CDS template + <eos>, no padding; species ids uniform), weak scaling.
+  --config 3: 4096 sequences x 1024 tokens in all, rank r takes sequences
+      [r*4096/N, (r+1)*4096/N) in micro-batches of 256 (strong scaling); a step is one pass over
+      the rank's whole shard.
+  --config 4 (= --mode train): masked-LM optimiser step (forward, loss, backward, gradient mean
+      over ranks, AdamW).
+bf16 operands with fp32 accumulation, weights random-initialised like the reference's training
+module (no checkpoint is available offline).  The step covers the embedding gather, 12 encoder
+layers, the final LayerNorm, the LM and structure heads and the synonymous-codon decode kernel;
+inputs are resident in HBM before the clock starts.
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel family (the MFMA
-GEMM): achieved = algorithmic FLOPs (2*M*N*K summed over its launches) / summed device time
-of those launches, taken from HIP events that bracket every GEMM launch inside the timed
-region.  `cpu_baseline` is the CPU oracle (torch fp32, the reference's op sequence) timed on
-a bounded sample of the same workload on the host cores.
+Ranks: under torchrun (WORLD_SIZE set) this process is one rank.  Without it, --gpus N > 1 makes
+this process a launcher: before anything touches the GPU it starts N copies of itself, one per
+GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, and returns their exit
+status.  Every rank runs its own batch (no data-path collective), the slowest rank's time is used.
+
+Rank 0 prints ONE JSON line.  `value` comes from steps timed with the per-kernel timers OFF; a
+second pass of the same steps with the timers on gives the per-kernel numbers.  `roofline`
+describes the dominant kernel family (the MFMA GEMM): achieved = algorithmic FLOPs (2*M*N*K
+summed over its launches) / summed device time of those launches, from HIP events attached to
+every GEMM dispatch; `roofline_by_kernel` has the same for the other families.  `cpu_baseline` is
+the CPU oracle (torch fp32, the reference's op sequence) timed on a bounded sample of the same
+workload on the host cores.
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,6 +49,9 @@ from transcodon_amd import _lib, ops  # noqa: E402
 
 B_PER_GPU, SEQ_LEN = 256, 512
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16, MI355X
+PEAK_HBM_GBS = 8000.0          # HBM3E
+TRAFFIC_UNIT = ("L2 fill + write-back bytes per GEMM launch (TCC_EA read / write requests of a rocprofv3 --pmc "
+                "pass of this command, committed under profiles/; Infinity-Cache hits are counted in it)")
 FLOPS_PER_TOKEN = lambda T: 12 * (14155776 + 3072 * T) + 2379264   # forward, E=768 L=12
 
 
@@ -87,7 +103,7 @@ def cpu_baseline(sd_cpu, tok, species, codes_per_seq, threads):
             "sample": f"{n_seq} seqs x {t.shape[1]} tokens x {iters} iters, torch fp32 oracle forward + decode, {dt:.1f} s"}
 
 
-def bench_train(args, world, rank, dev, dist_on):
+def bench_train(args, world, rank, dev, dist_on, rccl_ranks=1):
     """One step = forward, masked-LM loss, backward, gradient all-reduce (N > 1) and AdamW over
     one micro-batch per GPU (pretraining.py:94-134 with accumulate_grad_batches = 1)."""
     import torch.distributed as dist
@@ -123,24 +139,39 @@ def bench_train(args, world, rank, dev, dist_on):
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+
+    def timed(first_step, sync_grads=True):
+        out = []
+        flat.grad_sync.enabled = sync_grads
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out.append(step(first_step + i))
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist_on:
+            dist.barrier()
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        flat.grad_sync.enabled = True
+        return el, out
+
+    lib.tc_prof_enable(0)
+    elapsed, losses = timed(args.warmup)                        # the headline: no per-kernel timers
     lib.tc_prof_reset()
     lib.tc_prof_enable(1)
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        losses.append(step(args.warmup + i))
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        dist.barrier()
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed_prof, _ = timed(args.warmup + args.steps)           # instrumented pass
     lib.tc_prof_enable(0)
     n, ms, flops = _lib.prof_collect(_lib.PROF_GEMM)
     an, ams, aflops = _lib.prof_collect(_lib.PROF_ATTN)
+    exposed_ms = None
+    if dist_on:
+        # the same steps without the gradient exchange (ranks drift apart: timing only, run last)
+        elapsed_local, _ = timed(args.warmup + 2 * args.steps, sync_grads=False)
+        exposed_ms = round(1e3 * (elapsed - elapsed_local) / args.steps, 3)
     if rank == 0:
         tokens_total = world * B * T * args.steps
         gemm_tflops = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -148,6 +179,7 @@ def bench_train(args, world, rank, dev, dist_on):
         # forward 2 and backward 7 matrix products of 2*T*64 flops per token, head and layer
         step_flops = 3 * (12 * 14155776 + 2379264) + 12 * 3072 * T * 4.5
         model_tflops = tokens_total / world * step_flops / elapsed / 1e12
+        pmc = latest_profile("pmc_traffic_train")
         result = {
             "metric": "MLM training tokens/sec (fwd+bwd+AdamW)", "value": round(tokens_total / elapsed, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -156,19 +188,26 @@ def bench_train(args, world, rank, dev, dist_on):
             "config": {"workload": f"configs[3]: masked-LM optimiser step, {B} seqs x {T} tokens per GPU, 25 % "
                                    "positions selected (80/10/10) on the device each step, AdamW lr 2e-4 wd 0.1, gradient mean over ranks",
                        "seqs_per_gpu": B, "seq_len": T, "parallelism": f"data-parallel x{world}",
+                       "rccl_ranks": rccl_ranks,
+                       "gradient_mean_bytes_per_step": int(flat.grad.numel()) * 4 if world > 1 else 0,
+                       "exposed_communication_ms_per_step": exposed_ms,
+                       "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3),
                        "first_loss": round(float(losses[0]), 4), "last_loss": round(float(losses[-1]), 4)},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel / gemm_tn256x_kernel (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
-                         "traffic": pmc_traffic("r01_pmc_traffic_train.json"),
-                         "mfma_busy_pmc": pmc_mfma_busy("r01_pmc_traffic_train.json"),
-                         "traffic_unit": "HBM bytes per GEMM launch (PMC pass of this command, committed under profiles/)",
+                         "traffic": pmc_traffic(pmc) if pmc else None,
+                         "mfma_busy_pmc": pmc_mfma_busy(pmc) if pmc else None,
+                         "traffic_unit": TRAFFIC_UNIT, "traffic_source": pmc and "profiles/" + pmc,
                          "launches": n,
                          "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
                          "whole_step_tflops": round(model_tflops, 2),
                          "whole_step_frac": round(model_tflops / PEAK_BF16_TFLOPS, 4)},
-            "kernels": {"gemm_ms_per_step": round(ms / args.steps, 3), "attn_ms_per_step": round(ams / args.steps, 3),
-                        "attn_tflops": round(aflops / (ams * 1e-3) / 1e12, 2) if ams > 0 else None},
+            "roofline_by_kernel": {"attn": {"bound": "mfma", "achieved": round(aflops / (ams * 1e-3) / 1e12, 2) if ams > 0 else None,
+                                            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": round(aflops / (ams * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if ams > 0 else None,
+                                            "ms_per_step": round(ams / args.steps, 3)},
+                                   "gemm": {"ms_per_step": round(ms / args.steps, 3)}},
         }
         print(json.dumps(result))
     if dist_on:
@@ -202,81 +241,201 @@ def pmc_traffic(path, prefix="gemm"):
     return round(sum((v["read_bytes"] + v["write_bytes"]) * v["dispatches"] for v in sel) / n)
 
 
+def latest_profile(stem):
+    """Newest committed counter summary profiles/rNN_<stem>.json (None if there is none)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r??_{stem}.json")))
+    return os.path.basename(hits[-1]) if hits else None
+
+
+def launch_ranks(n, argv):
+    """Start n copies of this script, one rank per GPU, and return the worst exit status.  Runs in a
+    process that has not touched the GPU (importing torch does not)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for pr in list(pending):
+                code = pr.poll()
+                if code is None:
+                    continue
+                pending.remove(pr)
+                if code != 0:
+                    rc = rc or code
+                    for other in pending:          # a failed rank would leave the others at a barrier
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
+def sequence_batch(idx, T, seed):
+    """Sequences idx (global indices) of the config-3 workload: every sequence has its own generator
+    stream, so a rank builds only its shard."""
+    toks, sps, codes, offs, row0 = [], [], [], [0], []
+    for k, i in enumerate(idx):
+        t, sp, c, o, r0 = synthetic_batch(1, T, seed=(seed, int(i)))
+        toks.append(t[0]); sps.append(sp[0]); codes.append(c)
+        offs.append(offs[-1] + int(o[1])); row0.append(k * T + int(r0[0]))
+    return (np.stack(toks), np.array(sps, np.int32), b"".join(codes), np.array(offs, np.int32),
+            np.array(row0, np.int32))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=("infer", "train"), default="infer",
-                    help="infer: forward + decode (headline metric); train: masked-LM optimiser step")
+    ap.add_argument("--config", type=int, choices=(2, 3, 4, 5), default=2,
+                    help="BASELINE.json configs[] entry (1-based): 2 = 256 x 512 forward (headline), "
+                         "3 = 4096 x 1024 batch-sharded, 4 = masked-LM step, 5 = varlen embedding extraction")
+    ap.add_argument("--mode", choices=("infer", "train"), default=None,
+                    help="train = --config 4 (kept for older command lines)")
     ap.add_argument("--train-batch", type=int, default=64)
     ap.add_argument("--train-seq-len", type=int, default=1024)
+    ap.add_argument("--n-seqs", type=int, default=None,
+                    help="config 3 / 5: total number of sequences (default 4096 / 100000)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print this rank's identity and exit before any GPU call (launcher test)")
     args = ap.parse_args()
+    if args.mode == "train":
+        args.config = 4
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
+    if args.dry_run:
+        print(json.dumps({"dry_run": True, "rank": rank, "local_rank": local_rank, "world": world,
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+                          "config": args.config}), flush=True)
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = 1
     if dist_on:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                      # the rank count RCCL itself sees
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == dist.get_world_size() == world
 
-    if args.mode == "train":
-        return bench_train(args, world, rank, dev, dist_on)
+    if args.config == 4:
+        return bench_train(args, world, rank, dev, dist_on, rccl_ranks)
+    if args.config == 5:
+        from transcodon_amd.bench_varlen import bench_varlen
+        return bench_varlen(args, world, rank, dev, dist_on, rccl_ranks)
 
-    B, T = B_PER_GPU, SEQ_LEN
     model = ta.ProteinBertModel(ta.default_args(), ta.Alphabet.from_architecture("CodonModel"))
     ta.init_weights(model, seed=1234)
     sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.to(dev).eval().set_compute_dtype(torch.bfloat16)
     model.check_indices = False          # inputs are generated in range; avoids a host sync per step
 
-    tok_np, sp_np, codes, offs, row0 = synthetic_batch(B, T, seed=1234 + rank)
-    tok = torch.from_numpy(tok_np).to(dev)
-    sp = torch.from_numpy(sp_np).to(dev)
-    aa_dev = torch.frombuffer(bytearray(codes), dtype=torch.uint8).to(dev)
-    offs_dev, row0_dev = torch.from_numpy(offs).to(dev), torch.from_numpy(row0).to(dev)
+    if args.config == 2:
+        B, T, n_micro = B_PER_GPU, SEQ_LEN, 1
+        tok_np, sp_np, codes, offs, row0 = synthetic_batch(B, T, seed=1234 + rank)
+        n_total = world * B
+    else:
+        # config 3: strong scaling over a fixed set of sequences, micro-batches of 256
+        from transcodon_amd.parallel import shard_range
+        T, n_total = 1024, args.n_seqs or 4096
+        lo, hi = shard_range(n_total, rank, world)
+        tok_np, sp_np, codes, offs, row0 = sequence_batch(range(lo, hi), T, seed=1235)
+        B = min(256, hi - lo)
+        n_micro = (hi - lo + B - 1) // B
+    host = {"tok": torch.from_numpy(tok_np).pin_memory(), "sp": torch.from_numpy(sp_np).pin_memory(),
+            "aa": torch.frombuffer(bytearray(codes), dtype=torch.uint8).pin_memory(),
+            "offs": torch.from_numpy(offs).pin_memory(), "row0": torch.from_numpy(row0).pin_memory()}
+    d = {k: v.to(dev) for k, v in host.items()}
+    n_seq = tok_np.shape[0]
+    bases_host = torch.empty(3 * len(codes), dtype=torch.uint8).pin_memory()
 
-    def step():
+    # per micro-batch views / rebased offsets, made before the clock starts
+    mbs = []
+    for i in range(n_micro):
+        lo_s, hi_s = i * B, min((i + 1) * B, n_seq)
+        a0, a1 = int(offs[lo_s]), int(offs[hi_s])
+        mbs.append((d["tok"][lo_s:hi_s], d["sp"][lo_s:hi_s], d["aa"][a0:a1],
+                    (d["offs"][lo_s:hi_s + 1] - a0).contiguous(), (d["row0"][lo_s:hi_s] - lo_s * T).contiguous(),
+                    a0, a1))
+
+    def micro(i):
+        """Forward + decode of micro-batch i of this rank's shard; returns the decoded bases."""
+        tok_i, sp_i, aa_i, offs_i, row0_i, a0, a1 = mbs[i]
         with torch.no_grad():
-            out = model(tok, sp)
-        return ops.codon_decode(out["logits"].view(B * T, -1), aa_dev, offs_dev, row0_dev)
+            out = model(tok_i, sp_i)
+        return ops.codon_decode(out["logits"].view(tok_i.shape[0] * T, -1), aa_i, offs_i, row0_i), a0, a1
+
+    def step(host_io=False):
+        if host_io:      # token ids, species and residues come from the host; decoded bases go back
+            for k in ("tok", "sp", "aa", "offs", "row0"):
+                d[k].copy_(host[k], non_blocking=True)
+        for i in range(n_micro):
+            bases, a0, a1 = micro(i)
+            if host_io:
+                bases_host[3 * a0:3 * a1].copy_(bases, non_blocking=True)
+        return bases
+
+    def timed(n, **kw):
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            last = step(**kw)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist_on:
+            dist.barrier()
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el, last
 
     lib = _lib.load()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    lib.tc_prof_enable(0)
+    elapsed, bases = timed(args.steps)                      # the headline: no per-kernel timers
+    elapsed_io, _ = timed(args.steps, host_io=True)         # the same with H2D of the inputs and D2H of the bases
     lib.tc_prof_reset()
     lib.tc_prof_enable(1)
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        bases = step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        dist.barrier()
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed_prof, _ = timed(args.steps)                     # instrumented pass: per-kernel device times
     lib.tc_prof_enable(0)
     prof = {name: _lib.prof_collect(kind) for name, kind in
             (("gemm", _lib.PROF_GEMM), ("attn", _lib.PROF_ATTN), ("layernorm", _lib.PROF_LAYERNORM),
              ("embed", _lib.PROF_EMBED), ("head", _lib.PROF_HEAD), ("decode", _lib.PROF_DECODE))}
 
-    # sanity: the decoded bases of the last step translate back to the proteins
+    # sanity: the decoded bases of the last micro-batch translate back to its proteins
     flat = bytes(bases.cpu().numpy()).decode("ascii")
     from transcodon_amd.sequence import CODON_TO_AA
-    first = "".join(CODON_TO_AA[flat[i:i + 3]] for i in range(0, 3 * int(offs[1]), 3))
-    assert first.replace("#", "_") == "".join(ops.AA_ORDER[c] for c in codes[:int(offs[1])])
+    lo_s = (n_micro - 1) * B
+    a0, a1 = int(offs[lo_s]), int(offs[lo_s + 1])
+    first = "".join(CODON_TO_AA[flat[i:i + 3]] for i in range(0, 3 * (a1 - a0), 3))
+    assert first.replace("#", "_") == "".join(ops.AA_ORDER[c] for c in codes[a0:a1])
 
     if rank == 0:
-        tokens_total = world * B * T * args.steps
+        tokens_step = n_total * T                            # whole job, all ranks, one step
+        tokens_total = tokens_step * args.steps
         n, ms, flops = prof["gemm"]
         gemm_tflops = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         model_tflops = tokens_total / world * FLOPS_PER_TOKEN(T) / elapsed / 1e12
@@ -284,34 +443,49 @@ def main():
         M, E, F = B * T, 768, 3072
         per_layer = (M * E * 2 + 3 * E * E * 2 + M * 3 * E * 2) + (M * E * 2 + E * E * 2 + 2 * M * E * 4) + \
                     (M * E * 2 + F * E * 2 + M * F * 2) + (M * F * 2 + E * F * 2 + 2 * M * E * 4)
-        gemm_bytes = (12 * per_layer + M * E * 2 + 2 * E * E * 2 + M * 2 * E * 2) * args.steps
-        extra = {}
-        for name, unit, scale in (("attn", "TFLOP/s", 1e12), ("layernorm", "GB/s", 1e9),
-                                  ("embed", "GB/s", 1e9), ("head", "GB/s", 1e9), ("decode", "GB/s", 1e9)):
+        gemm_bytes = (12 * per_layer + M * E * 2 + 2 * E * E * 2 + M * 2 * E * 2) * args.steps * n_micro
+        by_kernel = {}
+        for name, bound, unit, scale, peak in (("attn", "mfma", "TFLOP/s", 1e12, PEAK_BF16_TFLOPS),
+                                               ("layernorm", "hbm", "GB/s", 1e9, PEAK_HBM_GBS),
+                                               ("embed", "hbm", "GB/s", 1e9, PEAK_HBM_GBS),
+                                               ("head", "hbm", "GB/s", 1e9, PEAK_HBM_GBS),
+                                               ("decode", "hbm", "GB/s", 1e9, PEAK_HBM_GBS)):
             cnt, kms, work = prof[name]
             if kms > 0:
-                extra[name] = {"launches": cnt, "avg_us": round(1e3 * kms / cnt, 2),
-                               "achieved": round(work / (kms * 1e-3) / scale, 2), "unit": unit}
+                ach = work / (kms * 1e-3) / scale
+                by_kernel[name] = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                                   "frac": round(ach / peak, 4), "launches": cnt, "avg_us": round(1e3 * kms / cnt, 2),
+                                   "ms_per_step": round(kms / args.steps, 3)}
+        pmc = latest_profile("pmc_traffic_infer")
+        workload = ("configs[1]: 256 seqs x 512 tokens (species + 5'UTR + CDS template) per GPU, "
+                    "forward + LM/structure heads + greedy codon decode") if args.config == 2 else \
+                   (f"configs[2]: {n_total} seqs x {T} tokens sharded over the ranks in micro-batches of {B}, "
+                    "forward + LM/structure heads + greedy codon decode")
         result = {
             "metric": "codon tokens/sec (fwd)", "value": round(tokens_total / elapsed, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[1]: 256 seqs x 512 tokens (species + 5'UTR + CDS template) per GPU, "
-                                   "forward + LM/structure heads + greedy codon decode",
-                       "seqs_per_gpu": B, "seq_len": T, "codons_per_s": round(tokens_total / elapsed / 3, 1),
-                       "weights": "random init N(0,0.02), 89.8M params", "parallelism": f"batch-sharded x{world}"},
+            "scaling": "weak" if args.config == 2 else "strong", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": workload,
+                       "seqs_per_gpu": n_seq, "seq_len": T, "micro_batch": B,
+                       "codons_per_s": round(tokens_total / elapsed / 3, 1),
+                       "weights": "random init N(0,0.02), 89.8M params", "parallelism": f"batch-sharded x{world}",
+                       "rccl_ranks": rccl_ranks,
+                       "with_host_io_tokens_per_s": round(tokens_total / elapsed_io, 1),
+                       "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3)},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel<bf16, EPI> (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
-                         "traffic": pmc_traffic("r01_pmc_traffic_infer.json"),
-                         "mfma_busy_pmc": pmc_mfma_busy("r01_pmc_traffic_infer.json"),
-                         "traffic_unit": "HBM bytes per GEMM launch (PMC pass of this command, committed under profiles/)",
+                         "traffic": pmc_traffic(pmc) if pmc and args.config == 2 else None,
+                         "mfma_busy_pmc": pmc_mfma_busy(pmc) if pmc and args.config == 2 else None,
+                         "traffic_unit": TRAFFIC_UNIT, "traffic_source": pmc and "profiles/" + pmc,
                          "algorithmic_bytes_per_launch": round(gemm_bytes / max(n, 1)),
                          "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
+                         "ms_per_step": round(ms / args.steps, 3),
                          "whole_forward_tflops": round(model_tflops, 2),
                          "whole_forward_frac": round(model_tflops / PEAK_BF16_TFLOPS, 4)},
-            "kernels": extra,
+            "roofline_by_kernel": by_kernel,
         }
         if world == 1 and not args.no_cpu_baseline:
             per_seq = []

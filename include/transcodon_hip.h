@@ -180,6 +180,7 @@ int tc_codon_decode(const float *logits, int ldl, const uint8_t *aa, const int32
  *   logits f32 [M,V]; labels int32 [M]; loss_sum f32[1] and count int32[1] are ACCUMULATED
  *   (zero them first); dlogits f32 [M,V] (may be NULL) receives
  *   (softmax - onehot) * grad_scale for counted rows and 0 elsewhere.
+ *   A label outside [0, V) other than -100 (torch raises on those) turns loss_sum into NaN.
  */
 int tc_ce_loss_fwd_bwd(const float *logits, const int32_t *labels, float *loss_sum,
                        int32_t *count, float *dlogits, float grad_scale, int M, int V,

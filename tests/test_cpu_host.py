@@ -189,3 +189,25 @@ def test_evaluation_metrics_against_reference_outputs(golden_dir):
     assert EV.gc_content("ACGU".replace("U", "T")) == 50.0
     with pytest.raises(KeyError):
         EV.cfd("ATGNNN", usage)
+
+
+def test_bench_launcher_starts_one_rank_per_gpu():
+    """`bench.py --gpus N` without WORLD_SIZE must itself start N ranks (before any GPU call) with the
+    rendezvous variables set; --dry-run makes every rank print its identity and exit."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for extra in ([], ["--config", "4"], ["--config", "3"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"] + extra,
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        assert sorted(l["rank"] for l in lines) == [0, 1]
+        assert all(l["world"] == 2 and l["local_rank"] == l["rank"] for l in lines)
+        assert len({l["master"] for l in lines}) == 1 and lines[0]["master"].startswith("127.0.0.1:")
+    # under torchrun (WORLD_SIZE set) the process is one rank and starts nothing
+    env.update(WORLD_SIZE="4", RANK="3", LOCAL_RANK="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["rank"] == 3 and lines[0]["world"] == 4

@@ -261,6 +261,20 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
     TC_REQUIRE(g->tok_table && g->species_table && g->lnf_g && g->lnf_b && g->w_heads && g->b_heads && g->lm_ln_g &&
                    g->lm_ln_b && g->lm_bias && g->st_ln_g && g->st_ln_b && g->st_w && g->st_bias,
                "tc_encoder_backward: null gradient pointer");
+    TC_REQUIRE(T <= d->rope_table_len, "tc_encoder_backward: T=%d exceeds the rope table (%d rows)", T,
+               d->rope_table_len);
+    TC_REQUIRE(tc_aligned16(workspace), "tc_encoder_backward: workspace must be 16-byte aligned");
+    // every pointer is checked before the first launch: a failure below can then only be a launch error
+    for (int l = 0; l < d->num_layers; ++l) {
+        const tc_layer_weights &lw = d->layers[l];
+        const tc_layer_grads &lg = g->layers[l];
+        TC_REQUIRE(lw.ln1_g && lw.ln1_b && lw.w_qkv && lw.b_qkv && lw.w_o && lw.b_o && lw.ln2_g && lw.ln2_b &&
+                       lw.w_fc1 && lw.b_fc1 && lw.w_fc2 && lw.b_fc2 && lw.rope_cos && lw.rope_sin,
+                   "tc_encoder_backward: layer %d has a null weight pointer", l);
+        TC_REQUIRE(lg.ln1_g && lg.ln1_b && lg.w_qkv && lg.b_qkv && lg.w_o && lg.b_o && lg.ln2_g && lg.ln2_b &&
+                       lg.w_fc1 && lg.b_fc1 && lg.w_fc2 && lg.b_fc2,
+                   "tc_encoder_backward: layer %d has a null gradient pointer", l);
+    }
     TrainWs w = carve(d, B, T, static_cast<char *>(workspace));
     if (w.total > workspace_bytes) {
         tc_set_error("tc_encoder_backward: workspace %zu bytes, need %zu", workspace_bytes, w.total);
@@ -316,9 +330,6 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
         const tc_layer_weights &lw = d->layers[l];
         const tc_layer_grads &lg = g->layers[l];
         LayerSaved &sv = w.L[l];
-        TC_REQUIRE(lg.ln1_g && lg.ln1_b && lg.w_qkv && lg.b_qkv && lg.w_o && lg.b_o && lg.ln2_g && lg.ln2_b &&
-                       lg.w_fc1 && lg.b_fc1 && lg.w_fc2 && lg.b_fc2,
-                   "tc_encoder_backward: layer %d has a null gradient pointer", l);
         // ---- feed-forward block: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) ----
         if (fuse)
             TC_TRY(linear_wgrad(d, w, TC_BF16, w.dyb, E, nullptr, sv.mid, w.ld_f, M, E, F, lg.w_fc2, nullptr, stream));

@@ -370,10 +370,17 @@ __global__ __launch_bounds__(256) void ce_kernel(const float *__restrict__ logit
                 for (int c = 0; c < V; ++c)
                     dlogits[(long)row * V + c] = (expf(l[c] - lse) - (c == y ? 1.f : 0.f)) * grad_scale;
             }
-        } else if (dlogits) {
-            for (int c = 0; c < V; ++c) dlogits[(long)row * V + c] = 0.f;
+        } else {
+            // Only -100 is "ignore" (torch.nn.CrossEntropyLoss raises on any other label outside
+            // [0, V)); a kernel cannot raise, so such a label poisons the loss with NaN instead of
+            // silently shrinking the denominator.
+            if (y != -100) loss = __builtin_nanf("");
+            if (dlogits)
+                for (int c = 0; c < V; ++c) dlogits[(long)row * V + c] = 0.f;
         }
     }
+    const bool poisoned = __ballot(loss != loss) != 0ull;
+    if (poisoned && (threadIdx.x & 63) == 0) atomicAdd(loss_sum, __builtin_nanf(""));
     loss = tc_wave_sum(loss);
     const unsigned long long voted = __ballot(cnt != 0);
     if ((threadIdx.x & 63) == 0) {

@@ -140,6 +140,16 @@ class GradientSync:
         except Exception as exc:      # a ctypes callback cannot propagate: keep it for finish()
             self.error = exc
 
+    def abandon(self):
+        """After a failed backward: wait for the exchanges already started (every rank issued the same
+        ones up to the failure) and forget them; the gradients of this step are not usable."""
+        pending, self._pending, self.error = self._pending, [], None
+        for work in pending:
+            try:
+                work.wait()
+            except Exception:      # noqa: BLE001 - the step is lost either way
+                pass
+
     def finish(self):
         """Wait (in stream order) for the exchanges started by on_ready and divide by the world size."""
         err, self.error = self.error, None

@@ -176,7 +176,11 @@ class EncoderTrainFunction(torch.autograd.Function):
         if sync is not None:
             # per-layer notification: the gradient exchange of a finished layer overlaps the rest
             cb = _lib.GRADS_READY_FN(lambda layer, _user: sync.on_ready(layer))
-            check(_lib.load().tc_encoder_backward_notify(*args, cb, None, _stream()), "tc_encoder_backward")
+            try:
+                check(_lib.load().tc_encoder_backward_notify(*args, cb, None, _stream()), "tc_encoder_backward")
+            except BaseException:
+                sync.abandon()      # exchanges already started must not be waited for by the next step
+                raise
             sync.finish()
         else:
             check(_lib.load().tc_encoder_backward(*args, _stream()), "tc_encoder_backward")
@@ -222,12 +226,21 @@ class _MlmLossFunction(torch.autograd.Function):
         return dl, None, ds, None, None
 
 
-def mlm_loss(logits, labels, struct_logits=None, struct_labels=None, struct_weight=0.4):
+def mlm_loss(logits, labels, struct_logits=None, struct_labels=None, struct_weight=0.4, struct_present=None):
     """pretraining.py:109-130: mean cross-entropy over labelled positions (ignore -100) plus
-    ``struct_weight`` times the structure cross-entropy when any structure label is set."""
+    ``struct_weight`` times the structure cross-entropy when any structure label is set.
+    A label outside [0, V) other than -100 makes the loss NaN (torch raises there).
+
+    ``struct_present``: whether any structure label is set, when the caller knows (a data feed
+    without structure labels passes False); None asks the device, which costs a host
+    synchronisation per call, like the reference's own ``(struct_label != -100).any()``."""
     if not logits.is_cuda:
         raise _lib.HipLibraryError("mlm_loss runs on the GPU only (no CPU fallback)")
-    if struct_labels is None or struct_logits is None or not bool((struct_labels != -100).any()):
+    if struct_labels is None or struct_logits is None:
+        struct_present = False
+    elif struct_present is None:
+        struct_present = bool((struct_labels != -100).any())
+    if not struct_present:
         struct_logits = struct_labels = None      # pretraining.py:122: the term exists only with labels
     return _MlmLossFunction.apply(logits, labels, struct_logits, struct_labels, struct_weight)
 
