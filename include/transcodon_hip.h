@@ -299,6 +299,18 @@ int tc_attn_bwd(int dtype, const void *qkv, int ldq, const uint64_t *key_words, 
                 const float *rope_cos, const float *rope_sin, float q_scale, int B, int T, int H, int D,
                 void *stream);
 
+/*
+ * tc_attn_bwd without a scratch argument, for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  delta lives in a 16 MiB array built into the library (one copy per GPU, held until the
+ * process ends): B*H*T must be <= 4 194 304 or the call fails with TC_EINVAL.  The call allocates and
+ * frees nothing.  All calls on one GPU share the array: calls that overlap on one GPU (different
+ * streams or threads) race; calls in stream order on one stream do not.  Results equal tc_attn_bwd's.
+ */
+int tc_attn_bwd_static(int dtype, const void *qkv, int ldq, const uint64_t *key_words, const void *out,
+                       const void *d_out, const float *lse, void *d_qkv, int ldg, const float *rope_cos,
+                       const float *rope_sin, float q_scale, int B, int T, int H, int D, void *stream);
+
 /* ---- whole-encoder convenience (one call per forward) ---------------------------- */
 
 typedef struct tc_layer_weights {

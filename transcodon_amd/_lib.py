@@ -95,6 +95,8 @@ _SIGNATURES = {
     "tc_attn_fwd_train": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "tc_attn_bwd": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_float,
                               C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "tc_attn_bwd_static": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_float,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "tc_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc), C.c_int, C.c_int]),
     "tc_encoder_forward": (C.c_int, [C.POINTER(EncoderDesc), vp, vp, C.c_int, C.c_int, vp, vp, vp,
                                      C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), vp, vp,

@@ -794,3 +794,45 @@ extern "C" int tc_attn_bwd(int dtype, const void *qkv, int ldq, const uint64_t *
     }
     return TC_OK;
 }
+
+// ---- allocation-free variant ------------------------------------------------------------------
+// tc_attn_bwd needs one scratch buffer beyond its inputs and outputs: delta[b,h,t] (f32).  Callers
+// that cannot allocate device memory (code under HIP graph capture, tight serving loops) get it from
+// this file-scope array instead: kStaticDeltaFloats floats (16 MiB) that every GPU the library runs
+// on holds until the process ends.  `scratch` is only a host-side stand-in for the symbol; the
+// device address comes from hipGetSymbolAddress, once per device.
+namespace {
+constexpr size_t kStaticDeltaFloats = (size_t)4 << 20;
+constexpr int kMaxDevices = 64;
+float *g_static_delta[kMaxDevices] = {};
+}  // namespace
+static __device__ __align__(256) float scratch[kStaticDeltaFloats];
+
+extern "C" int tc_attn_bwd_static(int dtype, const void *qkv, int ldq, const uint64_t *key_words, const void *out,
+                                  const void *d_out, const float *lse, void *d_qkv, int ldg, const float *rope_cos,
+                                  const float *rope_sin, float q_scale, int B, int T, int H, int D, void *stream) {
+    TC_REQUIRE(B > 0 && T > 0 && H > 0, "tc_attn_bwd_static: bad shape B=%d T=%d H=%d", B, T, H);
+    TC_REQUIRE((size_t)B * (size_t)H * (size_t)T <= kStaticDeltaFloats,
+               "tc_attn_bwd_static: B*H*T = %zu exceeds the built-in scratch of %zu floats; use tc_attn_bwd with a "
+               "caller-supplied delta buffer",
+               (size_t)B * H * T, kStaticDeltaFloats);
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        tc_set_error("tc_attn_bwd_static: cannot identify the current device");
+        return TC_ELAUNCH;
+    }
+    float *delta = __atomic_load_n(&g_static_delta[dev], __ATOMIC_ACQUIRE);
+    if (!delta) {
+        // first call on this device: every GPU has its own copy of the array at its own address
+        void *sym = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !sym) {
+            tc_set_error("tc_attn_bwd_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+            return TC_ELAUNCH;
+        }
+        delta = static_cast<float *>(sym);
+        __atomic_store_n(&g_static_delta[dev], delta, __ATOMIC_RELEASE);   // concurrent first calls store the same value
+    }
+    return tc_attn_bwd(dtype, qkv, ldq, key_words, out, d_out, lse, delta, d_qkv, ldg, rope_cos, rope_sin, q_scale, B, T,
+                       H, D, stream);
+}
