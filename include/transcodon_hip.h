@@ -366,6 +366,41 @@ int tc_encoder_forward(const tc_encoder_desc *desc, const int32_t *tokens, const
                        int n_rep, const int32_t *rep_layer, float *const *rep_out,
                        int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * Packed (variable-length) batches: n_seq sequences lie one after the other in the row dimension,
+ * sequence i in rows [cu[i], cu[i+1]); no padding rows exist, so GEMM / LayerNorm / head rows are
+ * sum(T_i) instead of B * T_max.  This is how the embedding extraction over coding sequences of very
+ * different lengths (transcodon/infer_embedding.py:17-148, one sequence per forward there) is batched.
+ *
+ * tc_gemm_qkv_packed   TC_EPI_QKV_ROPE where row m is rotated by table row pos[m] (int32 [M], device;
+ *                      pos[m] = m - cu[i]: positions restart per sequence, multihead_attention.py:358-360
+ *                      applied to each sequence on its own).  Every pos[m] must be < table_rows.
+ * tc_attn_fwd_packed   tc_attn_fwd per (sequence, query block): blocks is a device array of n_blocks
+ *                      entries {first row of the sequence, its length, query block index, 0} (int32 x 4),
+ *                      query blocks of tc_attn_packed_block_rows(dtype) rows, in any order; max_len = the
+ *                      longest sequence; flops feeds the timers only (4 H D sum T_i^2, or 0).
+ * tc_mean_pool_packed  tc_mean_pool with absolute first rows.
+ * tc_encoder_forward_packed   tc_encoder_forward on such a batch.  tokens / species_row / pos int32 [M]
+ *                      (species_row[m] = species id of row m's sequence); cu_seqlens_host is a HOST array
+ *                      [n_seq+1] used to validate lengths against the rope table and the block list.
+ *                      logits [M,vocab] or NULL (then the heads are skipped: embedding extraction);
+ *                      struct_logits [M,n_struct] or NULL; rep_last [M,E] or NULL.
+ *                      Workspace: tc_workspace_bytes(desc, 1, M).
+ */
+int tc_gemm_qkv_packed(int dtype, const void *A, int lda, const void *W, const float *bias, void *out, int ldo,
+                       int M, int N, int K, float q_scale, const float *rope_cos, const float *rope_sin,
+                       const int32_t *pos, int table_rows, int head_dim, void *stream);
+int tc_attn_packed_block_rows(int dtype);
+int tc_attn_fwd_packed(int dtype, const void *qkv, int ldq, const int32_t *blocks, int n_blocks, int max_len,
+                       void *out, int H, int D, double flops, void *stream);
+int tc_mean_pool_packed(const float *rep, const int32_t *row_start, const int32_t *len, float *pooled, int n_seq,
+                        int total_rows, int E, void *stream);
+int tc_encoder_forward_packed(const tc_encoder_desc *desc, const int32_t *tokens, const int32_t *species_row,
+                              const int32_t *pos, const int32_t *attn_blocks, int n_blocks,
+                              const int32_t *cu_seqlens_host, int n_seq, float *logits, float *struct_logits,
+                              float *rep_last, int32_t *status, void *workspace, size_t workspace_bytes,
+                              void *stream);
+
 /* ---- per-kernel timing for roofline reports -------------------------------------- */
 #define TC_PROF_GEMM 0
 #define TC_PROF_ATTN 1

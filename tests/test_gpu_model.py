@@ -317,20 +317,79 @@ def test_synthetic_batch_oracle_vs_hip_bf16(full_sd, full_bf16):
     assert float(d.max()) < 0.15
 
 
-def test_embedding_extraction_varlen(full_sd, full_f32):
-    """cfg5 in miniature: variable-length CDS batch, padded + key-masked; mean-pooled final
-    states against the oracle run one sequence at a time (as infer_embedding.py does)."""
+@pytest.mark.parametrize("packed", [True, False])
+def test_embedding_extraction_varlen(full_sd, full_f32, packed):
+    """cfg5 in miniature: variable-length CDS batch, packed (no padding rows) or padded + key-masked;
+    mean-pooled final states against the oracle run one sequence at a time (as infer_embedding.py does)."""
     rng = np.random.default_rng(1237)
     seqs = ["".join(rng.choice(list("ACGT"), size=3 * int(n))) for n in (30, 77, 31, 120, 64)]
     orgs = [int(x) for x in rng.integers(0, 1438, len(seqs))]
-    got = ta.extract_embeddings(full_f32, seqs, orgs, max_batch_tokens=400)
+    got = ta.extract_embeddings(full_f32, seqs, orgs, max_batch_tokens=400, packed=packed)
     assert got.shape == (len(seqs), 768)
     for i, s in enumerate(seqs):
         toks = O.batch_tokens([O.encode(["<cls>"] + list(s.replace("T", "U")) + ["<eos>"])])
         ref = O.forward(full_sd, O.FULL, toks, torch.tensor([orgs[i]]))["representations"][12][0, 1:-1].mean(0)
         np.testing.assert_allclose(got[i].numpy(), ref.numpy(), atol=2e-4)
-    full = ta.extract_embeddings(full_f32, seqs[:2], orgs[:2], pooled=False)
+    full = ta.extract_embeddings(full_f32, seqs[:2], orgs[:2], pooled=False, packed=packed)
     assert [t.shape for t in full] == [(90, 768), (231, 768)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_packed_forward_equals_padded_and_oracle(full_sd, full_f32, full_bf16, dtype):
+    """Packed variable-length forward (rows = sum of lengths, rotary positions restarting per sequence,
+    attention per (sequence, query block)) against the padded forward of the same sequences row for
+    row, and against the oracle one sequence at a time (infer_embedding.py:17-148 runs B = 1)."""
+    rng = np.random.default_rng(99)
+    lens = [92, 233, 95, 362, 600, 194, 257]             # below, at and above the query-block sizes (64 / 256)
+    m = full_f32 if dtype == torch.float32 else full_bf16
+    T = max(lens)
+    tok = np.full((len(lens), T), O.PAD, np.int64)
+    for b, n in enumerate(lens):
+        tok[b, :n] = [O.CLS] + list(rng.choice([5, 6, 7, 8, 9], n - 2)) + [O.EOS]
+    sp = rng.integers(0, 1438, len(lens))
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    flat = np.concatenate([tok[b, :n] for b, n in enumerate(lens)])
+    with torch.no_grad():
+        pad = m(torch.from_numpy(tok).to(DEV), torch.from_numpy(sp).to(DEV))
+        pk = m.forward_packed(torch.from_numpy(flat).to(DEV), sp, cu)
+        only_rep = m.forward_packed(torch.from_numpy(flat).to(DEV), sp, cu, want_logits=False)
+    assert set(only_rep) == {"representations"}
+    assert torch.equal(only_rep["representations"][12], pk["representations"][12])
+    tol = 2e-5 if dtype == torch.float32 else 0.03
+    for b, n in enumerate(lens):
+        rows = slice(int(cu[b]), int(cu[b + 1]))
+        for key in ("logits", "struct_label_output"):
+            d = (pk[key][rows] - pad[key][b, :n]).abs().max()
+            assert float(d) <= tol, (key, b, float(d))
+        d = (pk["representations"][12][rows] - pad["representations"][12][b, :n]).abs().max()
+        assert float(d) <= (1e-4 if dtype == torch.float32 else 0.15), (b, float(d))
+    for b in (0, 4, 6):
+        n = lens[b]
+        ref = O.forward(full_sd, O.FULL, torch.from_numpy(tok[b:b + 1, :n]), torch.from_numpy(sp[b:b + 1]))
+        rows = slice(int(cu[b]), int(cu[b + 1]))
+        _check(pk["logits"][rows].cpu().numpy()[None], ref["logits"].numpy(), np.ones((1, n), bool), dtype)
+    with pytest.raises(ValueError):
+        m.forward_packed(torch.from_numpy(flat).to(DEV), sp[:-1], cu)
+
+
+def test_packed_forward_large_batch_bf16(full_sd, full_bf16):
+    """A packed batch big enough for the persistent 256 x 256 GEMM kernels (row count not a multiple
+    of the tile): a few of its sequences against the oracle."""
+    rng = np.random.default_rng(1237)
+    lens = np.clip(3 * np.exp(rng.normal(5.0, 0.6, 300)).astype(int) + 2, 92, 2000)
+    lens = lens[np.cumsum(lens) <= 70000]
+    toks = [np.array([O.CLS] + list(rng.integers(5, 9, n - 2)) + [O.EOS]) for n in lens]
+    sp = rng.integers(0, 1438, len(lens))
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    assert cu[-1] > 65536 and cu[-1] % 256 != 0
+    with torch.no_grad():
+        pk = full_bf16.forward_packed(torch.from_numpy(np.concatenate(toks)).to(DEV), sp, cu)
+    for b in (0, len(lens) // 2, len(lens) - 1):
+        ref = O.forward(full_sd, O.FULL, torch.from_numpy(toks[b])[None], torch.from_numpy(sp[b:b + 1]))
+        rows = slice(int(cu[b]), int(cu[b + 1]))
+        _check(pk["logits"][rows].cpu().numpy()[None], ref["logits"].numpy(), np.ones((1, lens[b]), bool), torch.bfloat16)
+        d = np.abs(pk["representations"][12][rows].cpu().numpy() - ref["representations"][12][0].numpy())
+        assert float(d.max()) < 0.15
 
 
 def test_cli_csv_round_trip(tmp_path):

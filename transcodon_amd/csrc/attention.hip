@@ -30,6 +30,10 @@ struct AttnParams {
     int B, T, H, E;
     int nw;       // validity words per sequence = ceil(T/64)
     int nqb;      // query blocks per (b,h)
+    // Packed (variable-length) batches: sequences lie one after the other in the row dimension and
+    // blocks[i] = {first row of the sequence, its length, query block inside it, unused}; the grid
+    // is one workgroup per (block, head), no key is padding, B / T / nqb / words are not used.
+    const int4 *blocks;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -61,9 +65,9 @@ __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; } 
 
 constexpr int kMaxWords = 128;   // key tiles whose validity words are kept in LDS (T <= 8192)
 
-__device__ __forceinline__ uint64_t key_word(const AttnParams &p, int b, int kt) {
-    if (p.words) return p.words[(long)b * p.nw + kt];
-    const int rem = p.T - kt * 64;
+__device__ __forceinline__ uint64_t key_word(const AttnParams &p, int b, int kt, int Tn, int nw) {
+    if (p.words) return p.words[(long)b * nw + kt];
+    const int rem = Tn - kt * 64;
     return rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
 }
 
@@ -72,30 +76,44 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bf16_kernel(const AttnParams
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int id = tc_xcd_remap(blockIdx.x, gridDim.x);
-    const int qb = id % p.nqb;
-    const int bh = id / p.nqb;
-    const int h = bh % p.H, b = bh / p.H;
+    int qb, h, b, Tn;
+    long row_base;
+    if (p.blocks) {
+        const int4 blk = p.blocks[id / p.H];
+        h = id % p.H;
+        b = 0;
+        row_base = blk.x;
+        Tn = blk.y;
+        qb = blk.z;
+    } else {
+        qb = id % p.nqb;
+        const int bh = id / p.nqb;
+        h = bh % p.H;
+        b = bh / p.H;
+        Tn = p.T;
+        row_base = (long)b * p.T;
+    }
+    const int nw = (Tn + 63) >> 6;
     const int ql = lane & 31, h2 = lane >> 5;
     const int q0 = qb * (32 * kWaves) + wid * 32;
-    const bool q_live = q0 < p.T;                  // wave-uniform
-    const long row_base = (long)b * p.T;
+    const bool q_live = q0 < Tn;                   // wave-uniform
 
     // The key-validity words of this batch row go to LDS once: a global load consumed inside the
     // key loop would make the compiler wait for everything in flight, the K/V prefetch included.
     __shared__ uint64_t s_words[kMaxWords];
-    for (int i = threadIdx.x; i < p.nw && i < kMaxWords; i += 64 * kWaves) s_words[i] = key_word(p, b, i);
+    for (int i = threadIdx.x; i < nw && i < kMaxWords; i += 64 * kWaves) s_words[i] = key_word(p, b, i, Tn, nw);
     __syncthreads();
     auto tile_word = [&](int kt) { return s_words[kt]; };       // the host checks nw <= kMaxWords
 
     // number of key tiles up to the last one holding a valid key
-    int nkt = p.nw;
+    int nkt = nw;
     while (nkt > 0 && tile_word(nkt - 1) == 0ull) --nkt;
 
     // ---- Q fragments: B operand, lane (q, h2) holds Q[q][16 ks + 8 h2 .. +7] ----
     bf16x8 qf[4];
     {
         int qr = q0 + ql;
-        qr = qr < p.T ? qr : p.T - 1;
+        qr = qr < Tn ? qr : Tn - 1;
         const char *src = p.qkv + (row_base + qr) * p.ldq_bytes + (long)h * 128 + h2 * 16;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(src + ks * 32);
@@ -119,7 +137,7 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bf16_kernel(const AttnParams
     auto stage = [&](int buf, int kt) {
         char *kb = smem + buf * KV_STAGE_BYTES + wid * kPieces * 1024;
         char *vb = kb + KV_TILE_BYTES;
-        if (kt * 64 + 64 <= p.T) {
+        if (kt * 64 + 64 <= Tn) {
             const unsigned tile_off = (unsigned)((long)kt * 64 * p.ldq_bytes);
 #pragma unroll
             for (int i = 0; i < kPieces; ++i) {
@@ -131,7 +149,7 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bf16_kernel(const AttnParams
 #pragma unroll
             for (int i = 0; i < kPieces; ++i) {
                 int key = kt * 64 + s_row[i];
-                key = key < p.T ? key : p.T - 1;
+                key = key < Tn ? key : Tn - 1;
                 const unsigned row_off = (unsigned)(key * p.ldq_bytes);
                 tc_blds16(rsrc_kv, row_off + k_col[i], 0u, kb + i * 1024);
                 tc_blds16(rsrc_kv, row_off + v_col[i], 0u, vb + i * 1024);
@@ -296,7 +314,7 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bf16_kernel(const AttnParams
     // ---- epilogue: normalise, stage through the wave's LDS rows, store 16 B per lane ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (p.lse && h2 == 0 && q0 + ql < p.T)
+    if (p.lse && h2 == 0 && q0 + ql < Tn)
         p.lse[((long)b * p.H + h) * p.T + q0 + ql] =
             l_tot > 0.f ? (m_run + __log2f(l_tot)) * 0.69314718055994531f : INFINITY;
     __syncthreads();                       // every wave is done with the K/V stages
@@ -317,7 +335,7 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bf16_kernel(const AttnParams
         const int r = it * 8 + (lane >> 3), c = lane & 7;
         const u32x4 w = *reinterpret_cast<const u32x4 *>(ost + r * OST_LD + c * 16);
         const int q = q0 + r;
-        if (q < p.T)
+        if (q < Tn)
             *reinterpret_cast<u32x4 *>(p.out + (row_base + q) * p.ldo_bytes + (long)h * 128 + c * 16) = w;
     }
 }
@@ -331,13 +349,27 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) float ks[F32_KT][64];
     __shared__ __attribute__((aligned(16))) float vs[F32_KT][64];
     const int lane = threadIdx.x;
-    const int qb = blockIdx.x % p.nqb;
-    const int bh = blockIdx.x / p.nqb;
-    const int h = bh % p.H, b = bh / p.H;
-    const long row_base = (long)b * p.T;
+    int qb, h, b, Tn;
+    long row_base;
+    if (p.blocks) {                                // packed batch: see AttnParams::blocks
+        const int4 blk = p.blocks[blockIdx.x / p.H];
+        h = blockIdx.x % p.H;
+        b = 0;
+        row_base = blk.x;
+        Tn = blk.y;
+        qb = blk.z;
+    } else {
+        qb = blockIdx.x % p.nqb;
+        const int bh = blockIdx.x / p.nqb;
+        h = bh % p.H;
+        b = bh / p.H;
+        Tn = p.T;
+        row_base = (long)b * p.T;
+    }
+    const int nw = (Tn + 63) >> 6;
     int qi = qb * 64 + lane;
-    const bool q_ok = qi < p.T;
-    qi = q_ok ? qi : p.T - 1;
+    const bool q_ok = qi < Tn;
+    qi = q_ok ? qi : Tn - 1;
 
     float q[64], o[64];
     {
@@ -352,8 +384,8 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
     }
     float m_run = -INFINITY, l_run = 0.f;
 
-    for (int k0 = 0; k0 < p.T; k0 += F32_KT) {
-        const uint64_t word = key_word(p, b, k0 >> 6);
+    for (int k0 = 0; k0 < Tn; k0 += F32_KT) {
+        const uint64_t word = key_word(p, b, k0 >> 6, Tn, nw);
         const uint32_t bits = (uint32_t)(word >> (k0 & 63));
         if (bits == 0u) continue;                                   // uniform: no valid key here
         __syncthreads();
@@ -363,7 +395,7 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
             const int idx = i * 64 + lane;        // float4 index in the tile
             const int r = idx >> 4, c4 = idx & 15;
             int key = k0 + r;
-            key = key < p.T ? key : p.T - 1;
+            key = key < Tn ? key : Tn - 1;
             const float *rowp = reinterpret_cast<const float *>(p.qkv + (row_base + key) * p.ldq_bytes);
             *reinterpret_cast<f32x4 *>(&ks[r][c4 * 4]) =
                 *reinterpret_cast<const f32x4 *>(rowp + p.E + h * 64 + c4 * 4);
@@ -499,6 +531,54 @@ static int attn_fwd_impl(int dtype, const void *qkv, int ldq, const uint64_t *ke
     TC_CHECK_LAUNCH("tc_attn_fwd");
     return TC_OK;
 }
+
+// Packed batches: `blocks` (device, int32 x 4 per entry: first row of the sequence, its length, query
+// block index, 0) lists the n_blocks (sequence, query block) pairs; query blocks are q_block_rows rows.
+extern "C" int tc_attn_fwd_packed(int dtype, const void *qkv, int ldq, const int32_t *blocks, int n_blocks,
+                                  int max_len, void *out, int H, int D, double flops, void *stream) {
+    TC_REQUIRE(dtype == TC_BF16 || dtype == TC_F32, "tc_attn_fwd_packed: bad dtype %d", dtype);
+    TC_REQUIRE(qkv && out && blocks, "tc_attn_fwd_packed: null operand");
+    TC_REQUIRE(D == 64, "tc_attn_fwd_packed: head_dim %d unsupported (only 64)", D);
+    TC_REQUIRE(n_blocks > 0 && H > 0 && max_len > 0, "tc_attn_fwd_packed: bad shape");
+    const int E = H * D;
+    const int esz = dtype == TC_BF16 ? 2 : 4;
+    TC_REQUIRE(ldq >= 3 * E && (ldq * esz) % 16 == 0, "tc_attn_fwd_packed: ldq=%d too small or misaligned", ldq);
+    TC_REQUIRE(tc_aligned16(qkv) && tc_aligned16(out) && tc_aligned16(blocks),
+               "tc_attn_fwd_packed: operands must be 16-byte aligned");
+    TC_REQUIRE(dtype != TC_BF16 || (max_len + 63) / 64 <= kMaxWords,
+               "tc_attn_fwd_packed: a sequence of %d tokens exceeds the bf16 kernel's %d keys", max_len, kMaxWords * 64);
+    AttnParams p{};
+    p.qkv = static_cast<const char *>(qkv);
+    p.out = static_cast<char *>(out);
+    p.ldq_bytes = (long)ldq * esz;
+    p.ldo_bytes = (long)E * esz;
+    p.H = H; p.E = E;
+    p.blocks = reinterpret_cast<const int4 *>(blocks);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long grid = (long)n_blocks * H;
+    TC_REQUIRE(grid < (1L << 31), "tc_attn_fwd_packed: grid too large");
+    TcProfScope prof(TC_PROF_ATTN, s, flops);      // 4 * H * D * sum of T_s^2, known to the caller only
+    if (dtype == TC_BF16) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bf16_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS_BYTES);
+            if (e != hipSuccess) {
+                tc_set_error("tc_attn_fwd_packed: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                return TC_ELAUNCH;
+            }
+            attr_set = true;
+        }
+        TC_LAUNCH(attn_bf16_kernel, dim3((unsigned)grid), dim3(64 * kWaves), ATTN_LDS_BYTES, s, p);
+    } else {
+        TC_LAUNCH(attn_f32_kernel, dim3((unsigned)grid), dim3(64), 0, s, p);
+    }
+    TC_CHECK_LAUNCH("tc_attn_fwd_packed");
+    return TC_OK;
+}
+
+// rows per query block of tc_attn_fwd_packed's block list for an element type
+extern "C" int tc_attn_packed_block_rows(int dtype) { return dtype == TC_BF16 ? 32 * kWaves : 64; }
 
 extern "C" int tc_attn_scores(int dtype, const void *qkv, int ldq, const uint8_t *pad_flags,
                               float *scores, int B, int T, int H, int D, void *stream) {

@@ -154,3 +154,98 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
                                   struct_logits, M, E, d->n_struct, d->ln_eps, stream));
     return TC_OK;
 }
+
+// Packed (variable-length) forward: the sequences lie one after the other in the row dimension, no
+// padding row exists, so every row kernel and GEMM works on sum(T_s) rows.  Rotary positions restart
+// per sequence (pos), attention runs per (sequence, query block) from the block list.
+extern "C" int tc_encoder_forward_packed(const tc_encoder_desc *d, const int32_t *tokens, const int32_t *species_row,
+                                         const int32_t *pos, const int32_t *attn_blocks, int n_blocks,
+                                         const int32_t *cu_seqlens_host, int n_seq, float *logits,
+                                         float *struct_logits, float *rep_last, int32_t *status, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
+    TC_TRY(check_desc(d));
+    TC_REQUIRE(tokens && species_row && pos && attn_blocks && cu_seqlens_host && workspace,
+               "tc_encoder_forward_packed: null operand");
+    TC_REQUIRE(logits || rep_last, "tc_encoder_forward_packed: no output requested");
+    TC_REQUIRE(n_seq > 0 && cu_seqlens_host[0] == 0, "tc_encoder_forward_packed: cu_seqlens must start at 0");
+    const int qrows = tc_attn_packed_block_rows(d->dtype);
+    long want_blocks = 0;
+    int max_len = 0;
+    double attn_flops = 0.0;
+    for (int i = 0; i < n_seq; ++i) {
+        const long len = (long)cu_seqlens_host[i + 1] - cu_seqlens_host[i];
+        TC_REQUIRE(len > 0 && len <= d->rope_table_len,
+                   "tc_encoder_forward_packed: sequence %d has %ld tokens (1..%d, the rope table length)", i, len,
+                   d->rope_table_len);
+        want_blocks += (len + qrows - 1) / qrows;
+        if (len > max_len) max_len = (int)len;
+        attn_flops += 4.0 * d->H * 64.0 * (double)len * (double)len;
+    }
+    TC_REQUIRE(want_blocks == n_blocks, "tc_encoder_forward_packed: block list has %d entries, the lengths need %ld",
+               n_blocks, want_blocks);
+    const long Ml = cu_seqlens_host[n_seq];
+    TC_REQUIRE(Ml > 0 && Ml < (1L << 31), "tc_encoder_forward_packed: bad row count %ld", Ml);
+    TC_REQUIRE(!struct_logits || (d->st_ln_g && d->st_ln_b && d->st_w && d->st_bias && d->n_struct > 0),
+               "tc_encoder_forward_packed: structure head requested without its weights");
+    TC_REQUIRE(tc_aligned16(workspace) && tc_aligned16(attn_blocks),
+               "tc_encoder_forward_packed: workspace and block list must be 16-byte aligned");
+    const int M = (int)Ml, E = d->E, F = d->F, dt = d->dtype;
+    Workspace w = carve(d, 1, M, static_cast<char *>(workspace));
+    if (w.total > workspace_bytes) {
+        tc_set_error("tc_encoder_forward_packed: workspace %zu bytes, need %zu", workspace_bytes, w.total);
+        return TC_ENOSPC;
+    }
+    const bool bf = dt == TC_BF16;
+    auto ln = [&](const float *g, const float *b, float *extra_f32) {
+        return tc_layernorm_fwd(w.x, g, b, bf ? extra_f32 : static_cast<float *>(w.h), bf ? w.h : nullptr, M, E,
+                                d->ln_eps, stream);
+    };
+    for (int l = 0; l < d->num_layers; ++l) {
+        const tc_layer_weights &lw = d->layers[l];
+        TC_REQUIRE(lw.ln1_g && lw.ln1_b && lw.w_qkv && lw.b_qkv && lw.w_o && lw.b_o && lw.ln2_g && lw.ln2_b &&
+                       lw.w_fc1 && lw.b_fc1 && lw.w_fc2 && lw.b_fc2 && lw.rope_cos && lw.rope_sin,
+                   "tc_encoder_forward_packed: layer %d has a null weight pointer", l);
+    }
+    // one "sequence" per row for the gather: species_row[m] is the species of row m's sequence
+    TC_TRY(tc_embed_fwd(tokens, species_row, d->tok_table, d->species_table, w.x, nullptr, status, M, 1, E, d->vocab,
+                        d->n_species, d->pad_idx, stream));
+    for (int l = 0; l < d->num_layers; ++l) {
+        const tc_layer_weights &lw = d->layers[l];
+        TC_TRY(ln(lw.ln1_g, lw.ln1_b, nullptr));
+        TC_TRY(tc_gemm_qkv_packed(dt, w.h, E, lw.w_qkv, lw.b_qkv, w.qkv, 3 * E, M, 3 * E, E, 0.125f, lw.rope_cos,
+                                  lw.rope_sin, pos, d->rope_table_len, 64, stream));
+        TC_TRY(tc_attn_fwd_packed(dt, w.qkv, 3 * E, attn_blocks, n_blocks, max_len, w.h, d->H, 64, attn_flops, stream));
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.h, E, lw.w_o, lw.b_o, w.x, w.x, E, M, E, E, 0.f, nullptr, nullptr, 0,
+                       0, stream));
+        TC_TRY(ln(lw.ln2_g, lw.ln2_b, nullptr));
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_GELU, w.h, E, lw.w_fc1, lw.b_fc1, nullptr, w.mid, w.ld_mid, M, F, E, 0.f, nullptr,
+                       nullptr, 0, 0, stream));
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.x, w.x, E, M, E, F, 0.f, nullptr,
+                       nullptr, 0, 0, stream));
+    }
+    if (bf) {
+        TC_TRY(tc_layernorm_fwd(w.x, d->lnf_g, d->lnf_b, rep_last, (logits || !rep_last) ? w.h : nullptr, M, E, d->ln_eps,
+                                stream));
+    } else {
+        float *dst = logits ? static_cast<float *>(w.h) : rep_last;      // embedding extraction writes the result directly
+        TC_TRY(tc_layernorm_fwd(w.x, d->lnf_g, d->lnf_b, dst, nullptr, M, E, d->ln_eps, stream));
+        if (rep_last && dst != rep_last) {
+            hipError_t e = hipMemcpyAsync(rep_last, w.h, (size_t)M * E * 4, hipMemcpyDeviceToDevice,
+                                          static_cast<hipStream_t>(stream));
+            if (e != hipSuccess) {
+                tc_set_error("tc_encoder_forward_packed: representation copy: %s", hipGetErrorString(e));
+                return TC_ELAUNCH;
+            }
+        }
+    }
+    if (!logits) return TC_OK;              // embedding extraction needs no head
+    const int nheads = struct_logits ? 2 : 1;
+    TC_TRY(tc_gemm(dt, TC_EPI_BIAS_GELU, w.h, E, d->w_heads, d->b_heads, nullptr, w.mid, w.ld_mid, M, nheads * E, E, 0.f,
+                   nullptr, nullptr, 0, 0, stream));
+    TC_TRY(tc_head_logits_fwd(dt, w.mid, w.ld_mid, 0, d->lm_ln_g, d->lm_ln_b, d->tok_table, d->lm_bias, logits, M, E,
+                              d->vocab, d->ln_eps, stream));
+    if (struct_logits)
+        TC_TRY(tc_head_logits_fwd(dt, w.mid, w.ld_mid, E, d->st_ln_g, d->st_ln_b, d->st_w, d->st_bias, struct_logits, M, E,
+                                  d->n_struct, d->ln_eps, stream));
+    return TC_OK;
+}

@@ -37,6 +37,7 @@ struct GemmParams {
     char *out;
     const float *rope_cos;
     const float *rope_sin;
+    const int32_t *pos;    // TC_EPI_QKV_ROPE, optional: rotary position of every row (packed batches); else row % T
     const char *aux;       // TC_EPI_DGELU: pre-activation u, element type T, leading dimension ldo
     char *out2;            // TC_EPI_BIAS_GELU_SAVE: pre-activation output, element type T
     float *colsum;         // TC_EPI_DGELU, large tiles: column sums of the result are added here (f32 [N])
@@ -250,7 +251,7 @@ __device__ __forceinline__ void epilogue8(const GemmParams &p, int m, int n, int
             for (int j = 0; j < 8; ++j) v[j] *= p.q_scale;
         }
         if (section < 2) {
-            const int pos = m % p.T;
+            const int pos = p.pos ? p.pos[m] : m % p.T;
             const long t = (long)pos * (p.head_dim >> 1) + ((n % p.head_dim) >> 1);
             const f32x4 cs = *reinterpret_cast<const f32x4 *>(p.rope_cos + t);
             const f32x4 sn = *reinterpret_cast<const f32x4 *>(p.rope_sin + t);
@@ -601,8 +602,8 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
             const float qs = section == 0 ? p.q_scale : 1.0f;
             const int half = p.head_dim >> 1;
             // this lane's 4 columns of n-tile ni are rotary pairs pi(ni) + fgrp*2 + {0,1}
-            const int tile_pos0 = (tm * BM) % p.T;
-            const bool recur = sizeof(T) == 2 && tile_pos0 + BM <= p.T;
+            const int tile_pos0 = p.pos ? 0 : (tm * BM) % p.T;
+            const bool recur = sizeof(T) == 2 && !p.pos && tile_pos0 + BM <= p.T;
             // No sequence boundary inside the tile (recur): rows 16 apart differ by a fixed
             // angle, so only the first row's cos/sin are gathered (a gather touches 16 table
             // rows per load instruction, which is what makes it expensive) and the other seven
@@ -638,7 +639,9 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
                 } else {
 #pragma unroll
                     for (int mi = MI0; mi < MI1; ++mi) {
-                        const long row = (long)((mrow0 + mi_off<LAY>(mi)) % p.T) * half + pi;
+                        const int m = mrow0 + mi_off<LAY>(mi);
+                        const int rpos = p.pos ? p.pos[m < p.M ? m : p.M - 1] : m % p.T;
+                        const long row = (long)rpos * half + pi;
                         const f32x2 c = *reinterpret_cast<const f32x2 *>(p.rope_cos + row);
                         const f32x2 sn = *reinterpret_cast<const f32x2 *>(p.rope_sin + row);
                         const f32x4 v = acc[ni][mi] * qs;
@@ -1383,7 +1386,7 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
         // the alternating kernel's rotary epilogue steps through a tile by angle addition: no
         // sequence boundary inside a 256-row tile, head dimension 64
         bool use_alt = alt != 0;
-        if (EPI == TC_EPI_QKV_ROPE && (p.T % 256 != 0 || p.head_dim != 64)) use_alt = false;
+        if (EPI == TC_EPI_QKV_ROPE && (p.T % 256 != 0 || p.head_dim != 64 || p.pos)) use_alt = false;
         if (use_alt) {
             static bool attr_set_x = false;
             if (!attr_set_x) {
@@ -1445,7 +1448,7 @@ extern "C" void tc_debug_set_stamp_buffer(void *p) { g_stamps = static_cast<unsi
 static int gemm_impl(int dtype, int epilogue, const void *A, int lda, const void *W, const float *bias,
                      const float *residual, const void *aux, void *out, void *out2, int ldo, int M, int N,
                      int K, int splits, float q_scale, const float *rope_cos, const float *rope_sin, int T,
-                     int head_dim, void *stream) {
+                     int head_dim, void *stream, const int32_t *pos = nullptr) {
     TC_REQUIRE(dtype == TC_BF16 || dtype == TC_F32, "tc_gemm: bad dtype %d", dtype);
     const int esz = dtype == TC_BF16 ? 2 : 4;
     const int kt = 128 / esz;
@@ -1472,6 +1475,7 @@ static int gemm_impl(int dtype, int epilogue, const void *A, int lda, const void
     p.out2 = static_cast<char *>(out2);
     p.rope_cos = rope_cos;
     p.rope_sin = rope_sin;
+    p.pos = pos;
     p.lda_bytes = (long)lda * esz;
     p.ldw_bytes = (long)K * esz;
     p.ldo = ldo;
@@ -1536,6 +1540,16 @@ extern "C" int tc_gemm(int dtype, int epilogue, const void *A, int lda, const vo
     TC_REQUIRE(epilogue >= TC_EPI_BIAS && epilogue <= TC_EPI_QKV_ROPE, "tc_gemm: unknown epilogue %d", epilogue);
     return gemm_impl(dtype, epilogue, A, lda, W, bias, residual, nullptr, out, nullptr, ldo, M, N, K, 1, q_scale,
                      rope_cos, rope_sin, T, head_dim, stream);
+}
+
+// TC_EPI_QKV_ROPE for packed batches: row m is rotated by row pos[m] of the tables (pos int32 [M] on
+// the device, every entry below table_rows: the caller's contract, it is not checked on the device).
+extern "C" int tc_gemm_qkv_packed(int dtype, const void *A, int lda, const void *W, const float *bias, void *out, int ldo,
+                                  int M, int N, int K, float q_scale, const float *rope_cos, const float *rope_sin,
+                                  const int32_t *pos, int table_rows, int head_dim, void *stream) {
+    TC_REQUIRE(pos != nullptr && table_rows > 0, "tc_gemm_qkv_packed: needs the row positions and the table length");
+    return gemm_impl(dtype, TC_EPI_QKV_ROPE, A, lda, W, bias, nullptr, nullptr, out, nullptr, ldo, M, N, K, 1, q_scale,
+                     rope_cos, rope_sin, table_rows, head_dim, stream, pos);
 }
 
 extern "C" int tc_gemm_train(int dtype, int epilogue, const void *A, int lda, const void *W, const float *bias,

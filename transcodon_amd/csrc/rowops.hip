@@ -397,15 +397,18 @@ __global__ __launch_bounds__(256) void ce_kernel(const float *__restrict__ logit
 __global__ __launch_bounds__(256) void mean_pool_kernel(const float *__restrict__ rep,
                                                         const int32_t *__restrict__ start,
                                                         const int32_t *__restrict__ len,
-                                                        float *__restrict__ pooled, int T, int E) {
+                                                        float *__restrict__ pooled, int T, int E,
+                                                        int packed_rows) {
+    // packed_rows > 0: start[] holds absolute rows of a packed buffer of that many rows
     const int b = blockIdx.y;
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= E) return;
     int s0 = start[b], n = len[b];
     s0 = s0 < 0 ? 0 : s0;
-    if (s0 + n > T) n = T - s0;
+    const int limit = packed_rows > 0 ? packed_rows : T;
+    if (s0 + n > limit) n = limit - s0;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const float *base = rep + ((long)b * T + s0) * E + col;
+    const float *base = rep + ((packed_rows > 0 ? 0L : (long)b * T) + s0) * E + col;
     int t = 0;
     for (; t + 4 <= n; t += 4) {
 #pragma unroll
@@ -422,8 +425,22 @@ extern "C" int tc_mean_pool(const float *rep, const int32_t *start, const int32_
     TC_REQUIRE(rep && start && len && pooled, "tc_mean_pool: null operand");
     TC_REQUIRE(B > 0 && T > 0 && E > 0 && B <= 65535, "tc_mean_pool: bad shape B=%d T=%d E=%d", B, T, E);
     TC_LAUNCH(mean_pool_kernel, dim3((E + 255) / 256, B), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), rep, start, len, pooled, T, E);
+                       static_cast<hipStream_t>(stream), rep, start, len, pooled, T, E, 0);
     TC_CHECK_LAUNCH("tc_mean_pool");
+    return TC_OK;
+}
+
+extern "C" int tc_mean_pool_packed(const float *rep, const int32_t *row_start, const int32_t *len, float *pooled,
+                                   int n_seq, int total_rows, int E, void *stream) {
+    TC_REQUIRE(rep && row_start && len && pooled, "tc_mean_pool_packed: null operand");
+    TC_REQUIRE(n_seq > 0 && total_rows > 0 && E > 0, "tc_mean_pool_packed: bad shape n_seq=%d rows=%d E=%d", n_seq,
+               total_rows, E);
+    for (int first = 0; first < n_seq; first += 65535) {          // grid.y limit
+        const int n = n_seq - first < 65535 ? n_seq - first : 65535;
+        TC_LAUNCH(mean_pool_kernel, dim3((E + 255) / 256, n), dim3(256), 0, static_cast<hipStream_t>(stream), rep,
+                  row_start + first, len + first, pooled + (long)first * E, 0, E, total_rows);
+        TC_CHECK_LAUNCH("tc_mean_pool_packed");
+    }
     return TC_OK;
 }
 

@@ -96,22 +96,48 @@ def embed_sequence(model, utr_seq, sequence: Union[str, WithUtr_CodonSequence_in
 
 def extract_embeddings(model, cds_seqs: Sequence[str], organisms: Sequence[Union[int, str]],
                        max_batch_tokens: int = 1 << 17, max_positions: int = 6146,
-                       pooled: bool = True):
+                       pooled: bool = True, packed: bool = True):
     """Embedding extraction (reference transcodon/infer_embedding.py: representations[12] of
     `<cls> cds <eos>`, one sequence per call) for many coding sequences at once.
 
-    Sequences (DNA or RNA letters, T is read as U) are sorted by length, packed into padded
-    batches of at most ``max_batch_tokens`` tokens and run with key-padding-aware attention.
-    Returns a [N, E] float tensor on the CPU with the mean of the final-layer states over the
-    CDS positions (the pooling hinted at in infer_embedding.py:145), or, with pooled=False, a
-    list of [len_i, E] tensors of the CDS positions."""
+    Sequences (DNA or RNA letters, T is read as U) go through the model in batches of at most
+    ``max_batch_tokens`` tokens.  packed=True (default): the sequences of a batch are laid one
+    after the other without padding (ProteinBertModel.forward_packed), so the work is the sum of
+    the lengths; packed=False: sorted by length into right-padded batches with key-padding-aware
+    attention.  Returns a [N, E] float tensor on the CPU with the mean of the final-layer states
+    over the CDS positions (the pooling hinted at in infer_embedding.py:145), or, with
+    pooled=False, a list of [len_i, E] tensors of the CDS positions."""
     from .sequence import CodonSequence
     dev = _model_device(model)
     L = model.num_layers
     enc = [_ALPHABET.encode(CodonSequence("", s).seq)[:max_positions] for s in cds_seqs]
     species = [_species_id(o) for o in organisms]
-    order = sorted(range(len(enc)), key=lambda k: len(enc[k]))
     out = [None] * len(enc)
+    if packed:
+        import numpy as np
+        pos = 0
+        while pos < len(enc):
+            chunk, ntok = [], 0
+            while pos < len(enc) and (not chunk or ntok + len(enc[pos]) <= max_batch_tokens):
+                chunk.append(pos)
+                ntok += len(enc[pos])
+                pos += 1
+            cu = np.concatenate([[0], np.cumsum([len(enc[k]) for k in chunk])])
+            flat = torch.from_numpy(np.concatenate([np.asarray(enc[k], np.int32) for k in chunk]))
+            with torch.no_grad():
+                rep = model.forward_packed(flat.to(dev), [species[k] for k in chunk], cu,
+                                           want_logits=False)["representations"][L]
+            lens = np.maximum(np.diff(cu) - 2, 0)
+            if pooled:
+                p = ops.mean_pool_packed(rep, torch.from_numpy(cu[:-1] + 1).to(dev), torch.from_numpy(lens).to(dev)).cpu()
+                for r, k in enumerate(chunk):
+                    out[k] = p[r]
+            else:
+                rep = rep.cpu()
+                for r, k in enumerate(chunk):
+                    out[k] = rep[int(cu[r]) + 1:int(cu[r]) + 1 + int(lens[r])].clone()
+        return torch.stack(out) if pooled else out
+    order = sorted(range(len(enc)), key=lambda k: len(enc[k]))
     pos = 0
     while pos < len(order):
         width, chunk = 0, []

@@ -242,6 +242,79 @@ class ProteinBertModel(nn.Module):
             raise IndexError("token or species id out of range")
         return {"logits": logits, "struct_label_output": struct, "representations": reps}
 
+    def packed_layout(self, species_type_ids, cu_seqlens, device):
+        """Device-side index arrays of a packed batch (see forward_packed): rotary position and species
+        of every row, and the attention work list.  Depends only on the lengths and species, so a
+        caller that runs the same batch repeatedly builds it once."""
+        import numpy as np
+        cu = np.asarray(cu_seqlens, dtype=np.int64)
+        lens = np.diff(cu)
+        n_seq = len(lens)
+        if cu.ndim != 1 or n_seq < 1 or cu[0] != 0 or (lens <= 0).any():
+            raise ValueError("packed batch: cu_seqlens must start at 0 and increase")
+        sp = np.asarray(species_type_ids.cpu() if torch.is_tensor(species_type_ids) else species_type_ids, dtype=np.int64)
+        if sp.shape != (n_seq,):
+            raise ValueError("packed batch: one species id per sequence")
+        qrows = _lib.load().tc_attn_packed_block_rows(_lib.TC_BF16 if self._dtype() == torch.bfloat16 else _lib.TC_F32)
+        M = int(cu[-1])
+        pos = np.arange(M, dtype=np.int64) - np.repeat(cu[:-1], lens)
+        nb = (lens + qrows - 1) // qrows
+        seq_of_block = np.repeat(np.arange(n_seq), nb)
+        qb = np.arange(int(nb.sum())) - np.repeat(np.cumsum(nb) - nb, nb)
+        order = np.argsort(-lens[seq_of_block], kind="stable")          # longest sequences first: shorter tail
+        blocks = np.zeros((len(qb), 4), np.int32)
+        blocks[:, 0], blocks[:, 1], blocks[:, 2] = cu[seq_of_block][order], lens[seq_of_block][order], qb[order]
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(device)
+        return {"cu": np.ascontiguousarray(cu.astype(np.int32)), "n_seq": n_seq, "rows": M, "max_len": int(lens.max()),
+                "pos": up(pos), "species_row": up(np.repeat(sp, lens)), "blocks": up(blocks), "n_blocks": len(qb),
+                "dtype": self._dtype()}
+
+    def forward_packed(self, tokens, species_type_ids, cu_seqlens, want_logits=True, want_struct=True,
+                       want_representation=True, layout=None):
+        """Forward of a PACKED variable-length batch: ``tokens`` int [M] holds the sequences one after
+        the other (no padding), sequence i in rows [cu_seqlens[i], cu_seqlens[i+1]); ``species_type_ids``
+        int [n_seq]; ``cu_seqlens`` a host sequence of n_seq+1 ints starting at 0.  Every sequence is
+        computed exactly as a batch-of-one forward would (model.py:175-259 has no cross-sequence term;
+        rotary positions restart per sequence), but all row kernels and GEMMs see sum(T_i) rows.
+        Returns {"logits" [M,V], "struct_label_output" [M,3], "representations" {L: [M,E]}}; parts not
+        asked for are left out (want_logits=False skips both heads: embedding extraction).
+        ``layout``: a packed_layout() result for the same lengths and species (else built here)."""
+        if not tokens.is_cuda:
+            raise _lib.HipLibraryError("forward_packed runs on the MI355X kernels only (there is no CPU fallback)")
+        dev = tokens.device
+        lay = layout if layout is not None else self.packed_layout(species_type_ids, cu_seqlens, dev)
+        M, n_seq = lay["rows"], lay["n_seq"]
+        if tokens.ndim != 1 or tokens.numel() != M:
+            raise ValueError("forward_packed: tokens must be 1-D with cu_seqlens[-1] entries")
+        L, E = len(self.layers), self.args.embed_dim
+        dt = self._dtype()
+        if lay["dtype"] != dt:
+            raise ValueError("forward_packed: the layout was built for another compute dtype")
+        pk = self._packed(dt, lay["max_len"], dev)
+        lib = _lib.load()
+        tok32 = tokens.to(torch.int32).contiguous()
+        out = {}
+        logits = struct = rep = None
+        if want_logits:
+            logits = out["logits"] = torch.empty(M, self.alphabet_size, dtype=torch.float32, device=dev)
+            if want_struct:
+                struct = out["struct_label_output"] = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        if want_representation or not want_logits:
+            rep = torch.empty(M, E, dtype=torch.float32, device=dev)
+            out["representations"] = {L: rep}
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        need = lib.tc_workspace_bytes(C.byref(pk["desc"]), 1, M)
+        ws = self._get_workspace(need, dev)
+        p = lambda t: None if t is None else t.data_ptr()
+        check(lib.tc_encoder_forward_packed(
+            C.byref(pk["desc"]), tok32.data_ptr(), lay["species_row"].data_ptr(), lay["pos"].data_ptr(),
+            lay["blocks"].data_ptr(), lay["n_blocks"], lay["cu"].ctypes.data, n_seq, p(logits), p(struct), p(rep),
+            status.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+            "tc_encoder_forward_packed")
+        if self.check_indices and int(status.item()) != 0:
+            raise IndexError("token or species id out of range")
+        return out
+
     def _forward_train(self, tokens, species_type_ids):
         """Differentiable forward (the training_step call of pretraining.py:103): logits and
         structure logits carry the autograd graph; no representations are returned."""

@@ -127,6 +127,19 @@ def mean_pool(rep, start, length):
     return out
 
 
+def mean_pool_packed(rep, row_start, length):
+    """rep f32 [M,E] (packed rows); row_start, length int32 [n] -> pooled f32 [n,E] (tc_mean_pool_packed)."""
+    row_start = row_start.to(torch.int32).contiguous()
+    length = length.to(torch.int32).contiguous()
+    _dev(rep, row_start, length)
+    M, E = rep.shape
+    n = row_start.numel()
+    out = torch.empty(n, E, dtype=torch.float32, device=rep.device)
+    check(_lib.load().tc_mean_pool_packed(_p(rep), _p(row_start), _p(length), _p(out), n, M, E, _stream()),
+          "tc_mean_pool_packed")
+    return out
+
+
 def encode_amino_acids(aa_seq: str) -> bytes:
     """Protein letters -> tc_codon_decode codes; unknown letters raise KeyError like
     the reference's dict lookup (infer_utr.py:108)."""
