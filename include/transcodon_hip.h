@@ -174,6 +174,20 @@ int tc_codon_decode(const float *logits, int ldl, const uint8_t *aa, const int32
                     const int32_t *row0, uint8_t *bases, int n_seq, int n_aa_total, void *stream);
 
 /*
+ * Per-sequence integer statistics of decoded coding sequences (the output of tc_codon_decode, or any
+ * ASCII A/C/G/T|U bytes), from which the reference's offline metrics follow exactly: GC content
+ * (evaluation/gc.py:7-20), codon recovery against a second sequence set
+ * (evaluation/codon_recover_rate.py:125-148) and the rare-codon share CFD (evaluation/cfd.py:9-44).
+ *   bases      uint8 [3 * n_codons]   ref_bases  the same shape, or NULL
+ *   codon_off  int32 [n_seq+1]        codons of sequence s: [codon_off[s], codon_off[s+1])
+ *   codon_flags uint8 [64] or NULL    1 for every codon (index 16a+4b+c over A,C,G,T|U = 0..3) to count
+ *   counts     int32 [n_seq,4]        {G+C letters, codons equal to ref, flagged codons, 1 if a letter
+ *                                      outside ACGTU occurred}
+ */
+int tc_codon_stats(const uint8_t *bases, const uint8_t *ref_bases, const int32_t *codon_off,
+                   const uint8_t *codon_flags, int32_t *counts, int n_seq, void *stream);
+
+/*
  * Mean cross-entropy with ignore_index = -100 over rows of thin logits, forward and
  * (optionally) gradient.  Replaces nn.CrossEntropyLoss(reduction='mean',
  * ignore_index=-100) of pretraining.py:54-55,109-112,124-127.
@@ -501,6 +515,16 @@ int tc_mlm_loss(const float *logits, const int32_t *labels, const float *struct_
 int tc_mlm_mask(const int32_t *tokens, const int32_t *lens, int32_t *tokens_out, int32_t *labels,
                 int32_t *struct_labels, int B, int T, uint64_t seed, double mask_proportion, double mask_percent,
                 double leave_percent, int mask_idx, const int32_t *coding_ids, int n_coding, void *stream);
+
+/*
+ * Random crop and right-padding of an int batch on the device: what DataTrimmer and DataPadder
+ * (transcodon/pipeline.py:250-263, 300-309) do with token strings.  Row b keeps
+ * keep = min(lens[b], T_out) entries starting at start[b] (clamped to [0, lens[b] - keep]; NULL = 0);
+ * out[b, t] = in[b, start[b] + t] for t < keep, `fill` after it (pad_idx for tokens, -100 for labels);
+ * lens_out[b] (optional) = keep.  in [B,T_in], out [B,T_out], distinct buffers.
+ */
+int tc_crop_pad(const int32_t *in, int32_t *out, const int32_t *start, const int32_t *lens, int32_t *lens_out,
+                int B, int T_in, int T_out, int fill, void *stream);
 
 /*
  * One AdamW update over n contiguous f32 values, torch.optim.AdamW semantics (pretraining.py:64-70:

@@ -381,3 +381,31 @@ def test_ce_loss_matches_torch():
     assert int(cnt.item()) == n
     np.testing.assert_allclose(float(loss.item()) / n, float(ref), rtol=1e-5)
     np.testing.assert_allclose(dl.cpu().numpy(), lg.grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_codon_stats_kernel_equals_host_metrics(golden_dir):
+    """GC content, codon recovery and CFD from tc_codon_stats on the device against the host functions,
+    themselves pinned by outputs of the reference's evaluation scripts (tests/golden/evaluation.json)."""
+    import json
+    import os
+    from transcodon_amd import evaluation as EV
+    with open(os.path.join(golden_dir, "evaluation.json")) as fh:
+        g = json.load(fh)
+    usage = EV.CodonUsage({k: (v[0], v[1]) for k, v in g["codon_frequencies"].items()})
+    cases = [c for c in g["cases"] if len(c["dna"]) % 3 == 0 and len(c["other"]) >= len(c["dna"])]
+    assert len(cases) >= 3
+    dna = [c["dna"] for c in cases]
+    other = [c["other"][:len(c["dna"])] for c in cases]
+    off = np.concatenate([[0], np.cumsum([len(d) // 3 for d in dna])]).astype(np.int32)
+    up = lambda strs: torch.frombuffer(bytearray("".join(strs).encode()), dtype=torch.uint8).to(DEV)
+    m = EV.device_metrics(up(dna), torch.from_numpy(off), ref_bases=up(other), usage=usage, threshold=0.3)
+    for i, c in enumerate(cases):
+        assert m["gc"][i] == pytest.approx(c["gc"], rel=1e-12)
+        assert m["cfd"][i] == pytest.approx(c["cfd"], rel=1e-12)
+        assert m["recovery"][i] == pytest.approx(EV.codon_similarity(c["dna"], other[i]), rel=1e-12)
+    m5 = EV.device_metrics(up(dna), torch.from_numpy(off), usage=usage, threshold=0.5)
+    assert m5["recovery"] is None
+    for i, c in enumerate(cases):
+        assert m5["cfd"][i] == pytest.approx(c["cfd_05"], rel=1e-12)
+    with pytest.raises(KeyError):
+        EV.device_metrics(up(["ATGNNN"]), torch.tensor([0, 2], dtype=torch.int32))

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "tc_head_logits_fwd": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp,
                                      C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "tc_codon_decode": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "tc_codon_stats": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp]),
     "tc_ce_loss_fwd_bwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp]),
     "tc_mean_pool": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "tc_gemm_train": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int,
@@ -118,6 +119,7 @@ _SIGNATURES = {
     "tc_mlm_loss": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, vp]),
     "tc_mlm_mask": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_double,
                               C.c_int, vp, C.c_int, vp]),
+    "tc_crop_pad": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "tc_adamw_step": (C.c_int, [vp, vp, vp, vp, C.c_long] + [C.c_float] * 5 + [C.c_int, C.c_float, vp]),
     "tc_prof_enable": (C.c_int, [C.c_int]),
     "tc_prof_reset": (C.c_int, []),

@@ -418,7 +418,59 @@ __global__ __launch_bounds__(256) void mean_pool_kernel(const float *__restrict_
     pooled[(long)b * E + col] = n > 0 ? ((acc[0] + acc[1]) + (acc[2] + acc[3])) / (float)n : 0.f;
 }
 
+// ---- per-sequence codon statistics of decoded bases ----------------------------------------------
+// One workgroup per sequence over its codons [off[s], off[s+1]); integer counts only, so the ratios
+// the caller forms equal those of a host loop exactly.
+__global__ __launch_bounds__(256) void codon_stats_kernel(const uint8_t *__restrict__ bases,
+                                                          const uint8_t *__restrict__ ref,
+                                                          const int32_t *__restrict__ off,
+                                                          const uint8_t *__restrict__ flag64,
+                                                          int32_t *__restrict__ out) {
+    __shared__ int acc[4];
+    if (threadIdx.x < 4) acc[threadIdx.x] = 0;
+    __syncthreads();
+    const int s = blockIdx.x;
+    const int first = off[s], last = off[s + 1];
+    int gc = 0, match = 0, flagged = 0, bad = 0;
+    for (int i = first + threadIdx.x; i < last; i += 256) {
+        int idx = 0;
+        bool same = ref != nullptr;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint8_t c = bases[3L * i + j];
+            const int v = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : (c == 'T' || c == 'U') ? 3 : -1;
+            gc += (c == 'G' || c == 'C');
+            if (v < 0) bad = 1;
+            idx = idx * 4 + (v < 0 ? 0 : v);
+            if (ref) same = same && ref[3L * i + j] == c;
+        }
+        match += same;
+        if (flag64) flagged += flag64[idx];
+    }
+    gc = (int)tc_wave_sum((float)gc);
+    match = (int)tc_wave_sum((float)match);
+    flagged = (int)tc_wave_sum((float)flagged);
+    bad = __ballot(bad != 0) != 0ull;
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&acc[0], gc);
+        atomicAdd(&acc[1], match);
+        atomicAdd(&acc[2], flagged);
+        atomicOr(&acc[3], bad);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) out[4 * s + threadIdx.x] = acc[threadIdx.x];
+}
+
 }  // namespace
+
+extern "C" int tc_codon_stats(const uint8_t *bases, const uint8_t *ref_bases, const int32_t *codon_off,
+                              const uint8_t *codon_flags, int32_t *counts, int n_seq, void *stream) {
+    TC_REQUIRE(bases && codon_off && counts && n_seq > 0, "tc_codon_stats: bad arguments");
+    TC_LAUNCH(codon_stats_kernel, dim3(n_seq), dim3(256), 0, static_cast<hipStream_t>(stream), bases, ref_bases,
+              codon_off, codon_flags, counts);
+    TC_CHECK_LAUNCH("tc_codon_stats");
+    return TC_OK;
+}
 
 extern "C" int tc_mean_pool(const float *rep, const int32_t *start, const int32_t *len, float *pooled,
                             int B, int T, int E, void *stream) {

@@ -458,6 +458,23 @@ __global__ __launch_bounds__(256) void mlm_mask_kernel(const int32_t *__restrict
     }
 }
 
+// ---- crop + right-pad of an int batch (DataTrimmer / DataPadder, pipeline.py:250-263, 300-309) --------
+__global__ __launch_bounds__(256) void crop_pad_kernel(const int32_t *__restrict__ in, int32_t *__restrict__ out,
+                                                       const int32_t *__restrict__ start,
+                                                       const int32_t *__restrict__ lens, int32_t *lens_out, int T_in,
+                                                       int T_out, int fill) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T_out) return;
+    int n = lens[b];
+    n = n < 0 ? 0 : (n > T_in ? T_in : n);
+    int s0 = start ? start[b] : 0;
+    const int keep = n < T_out ? n : T_out;
+    s0 = s0 < 0 ? 0 : (s0 > n - keep ? n - keep : s0);
+    out[(long)b * T_out + t] = t < keep ? in[(long)b * T_in + s0 + t] : fill;
+    if (t == 0 && lens_out) lens_out[b] = keep;
+}
+
 }  // namespace
 
 extern "C" int tc_transpose_cast(int in_dtype, int out_dtype, const void *in, int ld_in, void *out_t, int ldt,
@@ -638,6 +655,16 @@ extern "C" int tc_mlm_loss(const float *logits, const int32_t *labels, const flo
     TC_LAUNCH(mlm_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, stats, counts, loss,
                        dlogits, n_dl, dstruct_logits, n_ds, struct_weight, upstream);
     TC_CHECK_LAUNCH("tc_mlm_loss");
+    return TC_OK;
+}
+
+extern "C" int tc_crop_pad(const int32_t *in, int32_t *out, const int32_t *start, const int32_t *lens,
+                           int32_t *lens_out, int B, int T_in, int T_out, int fill, void *stream) {
+    TC_REQUIRE(in && out && lens && in != out, "tc_crop_pad: null or aliased operand");
+    TC_REQUIRE(B > 0 && B <= 65535 && T_in > 0 && T_out > 0, "tc_crop_pad: bad shape B=%d T_in=%d T_out=%d", B, T_in, T_out);
+    TC_LAUNCH(crop_pad_kernel, dim3((T_out + 255) / 256, B), dim3(256), 0, static_cast<hipStream_t>(stream), in, out,
+              start, lens, lens_out, T_in, T_out, fill);
+    TC_CHECK_LAUNCH("tc_crop_pad");
     return TC_OK;
 }
 

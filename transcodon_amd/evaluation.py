@@ -91,3 +91,34 @@ def min_max_percentage(dna: str, usage: CodonUsage, window_size: int = 18) -> Li
             pmin = (avg - actual) / (avg - mn) * 100
         out = [float(v) for v in np.where(pmax >= 0, pmax, -pmin)]
     return out + [None] * int(window_size / 2)
+
+
+def device_metrics(bases, codon_off, ref_bases=None, usage: Optional[CodonUsage] = None, threshold: float = 0.3):
+    """GC content, codon recovery and CFD of many decoded sequences at once, on the GPU, straight
+    from tc_codon_decode's output: ``bases`` uint8 [3 * n_codons] (ASCII, CUDA tensor), ``codon_off``
+    int32 [n_seq+1].  Integer counts come from one kernel (tc_codon_stats); the ratios formed from
+    them equal gc_content / codon_similarity / cfd of the corresponding strings exactly.
+    Returns {"gc": [n_seq], "recovery": [n_seq] or None, "cfd": [n_seq] or None} as numpy arrays."""
+    import torch
+    from . import _lib
+    if not bases.is_cuda:
+        raise _lib.HipLibraryError("device_metrics needs the bases on the GPU (use the string functions on the host)")
+    off = codon_off.to(device=bases.device, dtype=torch.int32).contiguous()
+    n_seq = off.numel() - 1
+    flags = None
+    if usage is not None:
+        rel = np.nan_to_num(usage.relative, nan=np.inf)
+        flags = torch.from_numpy((rel < threshold).astype(np.uint8)).to(bases.device)
+    counts = torch.empty(n_seq, 4, dtype=torch.int32, device=bases.device)
+    ref = None if ref_bases is None else ref_bases.contiguous()
+    _lib.check(_lib.load().tc_codon_stats(bases.contiguous().data_ptr(), None if ref is None else ref.data_ptr(),
+                                          off.data_ptr(), None if flags is None else flags.data_ptr(),
+                                          counts.data_ptr(), n_seq, torch.cuda.current_stream().cuda_stream),
+               "tc_codon_stats")
+    c = counts.cpu().numpy().astype(np.float64)
+    if c[:, 3].any():
+        raise KeyError("sequence contains a letter outside ACGTU")
+    n = np.diff(off.cpu().numpy()).astype(np.float64)
+    return {"gc": c[:, 0] / (3 * n) * 100,
+            "recovery": None if ref is None else c[:, 1] / n,
+            "cfd": None if flags is None else c[:, 2] / n * 100}
