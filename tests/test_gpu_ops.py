@@ -323,6 +323,33 @@ def test_attention_online_softmax_rescale():
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_attention_lazy_running_maximum_staircase(dtype):
+    """The bf16 kernel moves its softmax offset only when a key tile's maximum exceeds it by more
+    than 2^8; scores that climb tile after tile (steps below and above that threshold, in both
+    directions) must still give the exact softmax.  Checked against float64 on every query."""
+    B, T, H = 2, 512, 1
+    g = torch.Generator().manual_seed(31)
+    q = torch.randn(B * T, 64, generator=g) * 0.05
+    k = torch.randn(B * T, 64, generator=g) * 0.05
+    v = torch.randn(B * T, 64, generator=g)
+    q[:, 0] = 1.0
+    # per 64-key tile a shift of the whole tile's scores, in natural-log units: +3.5 and +7 stay below the
+    # lazy threshold (8 in log2 units = 5.5 nats) cumulatively crossing it, -20 falls far below, +30 jumps
+    steps = torch.tensor([0.0, 3.5, 7.0, 4.0, -20.0, 30.0, 33.0, 12.0])
+    k[:, 0] = steps.repeat_interleave(64).repeat(B)
+    qkv = torch.cat([q, k, v], 1)
+    if dtype == torch.bfloat16:
+        qkv = _bf(qkv)
+    ref, _ = _attn_ref(qkv, B, T, H, None)
+    out = ops.attention(qkv.to(DEV, dtype), B, T, H).float().cpu()
+    tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), **tol)
+    o2, lse = ops.attention_train(qkv.to(DEV, dtype), B, T, H)
+    s = (qkv[:, :64].double().view(B, T, 64) @ qkv[:, 64:128].double().view(B, T, 64).transpose(1, 2))
+    np.testing.assert_allclose(lse.cpu().numpy()[:, 0], torch.logsumexp(s, -1).numpy(), rtol=1e-3, atol=2e-2)
+
+
 def test_attention_rejects_sequences_beyond_the_bf16_limit():
     """The bf16 kernels keep one validity word per 64 keys in LDS: 8192 keys at most; the call
     must fail with an error instead of reading past the table."""

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""A/B timing of two builds of libtranscodon_hip.so on the encoder's GEMM shapes, in ONE process with
+interleaved rounds (timings of separate processes or devices are not comparable).
+
+    python tools/gemm_ab.py [base.so] [new.so] [--only qkv,fc1,...] [--rounds 5]
+
+Defaults: tools/ab/libtc_base.so against transcodon_amd/csrc/libtranscodon_hip.so.  Shapes use the
+forward's leading dimensions (FFN intermediate rows 3136 elements apart).  Also checks that both
+builds produce the same result.
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from transcodon_amd import _lib  # noqa: E402
+
+
+def load(path):
+    lib = C.CDLL(path)
+    res, args = _lib._SIGNATURES["tc_gemm"]
+    lib.tc_gemm.restype, lib.tc_gemm.argtypes = res, args
+    lib.tc_last_error.restype = C.c_char_p
+    return lib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("base", nargs="?", default=os.path.join(ROOT, "tools", "ab", "libtc_base.so"))
+    ap.add_argument("new", nargs="?", default=os.path.join(ROOT, "transcodon_amd", "csrc", "libtranscodon_hip.so"))
+    ap.add_argument("--only", default="qkv,qkv_bias,out,fc1,fc1_bias,fc2")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--M", type=int, default=131072)
+    a = ap.parse_args()
+    libs = {"base": load(a.base), "new": load(a.new)}
+    dev = "cuda"
+    M, E, F, T = a.M, 768, 3072, 512
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(M, E, device=dev, generator=g).bfloat16()
+    mid = torch.randn(M, F + 64, device=dev, generator=g).bfloat16()
+    res = torch.randn(M, E, device=dev, generator=g)
+    ang = torch.arange(T, dtype=torch.float32)[:, None] * (1.0 / 10000 ** (torch.arange(0, 64, 2).float() / 64))[None]
+    cos, sin = ang.cos().to(dev).contiguous(), ang.sin().to(dev).contiguous()
+    strm = torch.cuda.current_stream().cuda_stream
+    # name: (A, lda, N, K, epilogue, ldo, f32 out)
+    shapes = {"qkv": (x, E, 3 * E, E, _lib.EPI_QKV_ROPE, 3 * E, False),
+              "qkv_bias": (x, E, 3 * E, E, _lib.EPI_BIAS, 3 * E, False),
+              "out": (x, E, E, E, _lib.EPI_BIAS_RESIDUAL, E, True),
+              "fc1": (x, E, F, E, _lib.EPI_BIAS_GELU, F + 64, False),
+              "fc1_bias": (x, E, F, E, _lib.EPI_BIAS, F + 64, False),
+              "fc2": (mid, F + 64, E, F, _lib.EPI_BIAS_RESIDUAL, E, True)}
+    for name in a.only.split(","):
+        A, lda, N, K, epi, ldo, f32 = shapes[name]
+        w = (torch.randn(N, K, device=dev, generator=g) * 0.03).bfloat16()
+        b = torch.randn(N, device=dev, generator=g) * 0.1
+        outs = {k: torch.zeros(M, ldo, device=dev, dtype=torch.float32 if f32 else torch.bfloat16) for k in libs}
+
+        def run(k):
+            rc = libs[k].tc_gemm(1, epi, A.data_ptr(), lda, w.data_ptr(), b.data_ptr(), res.data_ptr() if f32 else None,
+                                 outs[k].data_ptr(), ldo, M, N, K, 0.125, cos.data_ptr(), sin.data_ptr(), T, 64, strm)
+            assert rc == 0, libs[k].tc_last_error()
+
+        for k in libs:
+            run(k)
+        torch.cuda.synchronize()
+        same = torch.equal(outs["base"][:, :N], outs["new"][:, :N])
+        maxd = float((outs["base"][:, :N].float() - outs["new"][:, :N].float()).abs().max())
+        times = {k: [] for k in libs}
+        for _ in range(a.rounds):
+            for k in libs:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    run(k)
+                e1.record()
+                torch.cuda.synchronize()
+                times[k].append(e0.elapsed_time(e1) / a.iters * 1e3)
+        med = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
+        mn = {k: min(v) for k, v in times.items()}
+        print(f"{name:9s} N={N:4d} K={K:4d}: base {med['base']:7.1f} us (min {mn['base']:7.1f})  new {med['new']:7.1f} us "
+              f"(min {mn['new']:7.1f})  new/base {med['new'] / med['base']:.3f}  {2.0 * M * N * K / med['new'] / 1e6:7.1f} TF/s  "
+              f"identical={same} max|d|={maxd:.3g}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

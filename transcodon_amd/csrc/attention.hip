@@ -256,7 +256,12 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bf16_kernel(const AttnParams
         }
         float tmax = fmaxf(tm0, tm1);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * kLog2e;
-        const float m_new = fmaxf(m_run, tmax);
+        // Lazy running maximum: the offset only moves when a tile's maximum exceeds it by more than
+        // kLazy (log2 units), so P stays below 2^kLazy and the rescale of O (32 multiplies per lane)
+        // is skipped for nearly every tile.  Exact up to rounding: any per-query offset cancels in the
+        // final normalisation, which is done in fp32.
+        constexpr float kLazy = 8.0f;
+        const float m_new = (tmax > m_run + kLazy) ? tmax : m_run;     // m_run = -inf: the first valid tile sets it
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
         const f32x2 scale2 = {kLog2e, kLog2e}, neg_m2 = {-m_use, -m_use};

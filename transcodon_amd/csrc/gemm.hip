@@ -578,13 +578,15 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
                 const f32x4 c16 = *reinterpret_cast<const f32x4 *>(step_lds + p0);
                 const f32x4 s16 = *reinterpret_cast<const f32x4 *>(step_lds + 128 + p0);
 #pragma unroll
-                for (int mi = MI0; mi < MI1; ++mi) {
+                for (int mi = 0; mi < MI1; ++mi) {      // the recurrence starts at row block 0 whatever MI0 is
+                    if (mi >= MI0) {
 #pragma unroll
-                    for (int ni = NI0; ni < NI1; ++ni) {
-                        const int e = (ni & 1) * 2;
-                        const f32x4 v = acc[ni][mi] * qs;
-                        acc[ni][mi] = f32x4{v[0] * c[e] - v[1] * sn[e], v[1] * c[e] + v[0] * sn[e],
-                                            v[2] * c[e + 1] - v[3] * sn[e + 1], v[3] * c[e + 1] + v[2] * sn[e + 1]};
+                        for (int ni = NI0; ni < NI1; ++ni) {
+                            const int e = (ni & 1) * 2;
+                            const f32x4 v = acc[ni][mi] * qs;
+                            acc[ni][mi] = f32x4{v[0] * c[e] - v[1] * sn[e], v[1] * c[e] + v[0] * sn[e],
+                                                v[2] * c[e + 1] - v[3] * sn[e + 1], v[3] * c[e + 1] + v[2] * sn[e + 1]};
+                        }
                     }
                     if (mi + 1 < MI1) {
                         f32x4 cs = c16, ss = s16;
@@ -1119,6 +1121,31 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // Measured and left off (TC_GEMM_PIECES=1 builds it): the quarters make the epilogue 4-11 % SLOWER
+    // on the K = 768 shapes.  A wave's epilogue is bound by the latency of its exchange / store chains,
+    // not by vector issue: the two waves of a SIMD hide each other's latency when they run it side by
+    // side, which a quarter running beside the partner's MFMAs cannot.
+#ifndef TC_GEMM_PIECES
+#define TC_GEMM_PIECES 0
+#endif
+    // Quarter (mq, nq) of the previous tile's epilogue: run in the load slot of the phase whose MFMAs
+    // use that quarter's accumulators next, while the other wave group multiplies.  Spread over the
+    // four phases of a tile's first k-tile instead of one block with the matrix pipe idle.
+    auto finish_quarter = [&](int tm, int tn, auto mq_c, auto nq_c) {
+        constexpr int mq = decltype(mq_c)::value, nq = decltype(nq_c)::value;
+        const int mrow0 = tm * BM + wr * 64 + frow, ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);
+        epilogue256<T, EPI, kLay, 4 * mq, 4 * mq + 4, 2 * nq, 2 * nq + 2, EPI == TC_EPI_QKV_ROPE || kGeluTable>(
+            p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, lds_bias ? bias_slot : nullptr,
+            kGeluTable ? smem + ROPE_OFF : rope_slot, step_slot);
+#pragma unroll
+        for (int ni = 2 * nq; ni < 2 * nq + 2; ++ni)
+#pragma unroll
+            for (int mi = 4 * mq; mi < 4 * mq + 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    constexpr bool kQuarters = kPiece && TC_GEMM_PIECES && EPI != TC_EPI_BIAS_GELU_SAVE;
     // epilogue of tile `local` (bias from this wave's LDS copy), accumulators back to zero
     auto finish_tile = [&](int tm, int tn) {
         const int mrow0 = tm * BM + wr * 64 + frow, ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);
@@ -1223,7 +1250,9 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
                 stage_half(nxt + SLOT_A1, p.A, a1_src, (unsigned)c1_k * 128u);
                 if (++c1_k == p.nk) { c1_k = 0; if (++c1_tile < my_count) { advance(c1m, c1n); set_c1(); } }
             }
-            if constexpr (kPiece) {
+            if constexpr (kQuarters) {
+                if (after) finish_quarter(ptm, ptn, I0{}, I0{});
+            } else if constexpr (kPiece) {
                 if (after) {
                     TC_STAMP(e0);
                     finish_tile(ptm, ptn);
@@ -1250,6 +1279,9 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             const bool more = c2_tile < my_count;
             const unsigned koff2 = (unsigned)c2_k * 128u;
             if (more) stage_half(cur + SLOT_B0, p.W, b0_src, koff2);
+            if constexpr (kQuarters) {
+                if (after) finish_quarter(ptm, ptn, I0{}, I1{});
+            }
             read_b(1);
             TC_PH(4);
             TC_XBAR();
@@ -1259,6 +1291,9 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             TC_PH(6);
             // ---- phase 2 ----
             if (more) stage_half(cur + SLOT_A0, p.A, a0_src, koff2);
+            if constexpr (kQuarters) {
+                if (after) finish_quarter(ptm, ptn, I1{}, I1{});
+            }
             read_a(1);
             TC_PH(7);
             TC_XBAR();
@@ -1270,8 +1305,14 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             // The wait leaves in flight what was issued after this k-tile's A1: three half-tiles,
             // plus, in a tile's first k-tile, the previous tile's stores (when none of its rows
             // was masked, so that every store instruction was issued; the counter holds 63).
+            if constexpr (kQuarters) {
+                // the last quarter's stores go out before the wait, so that the count below (every
+                // operation younger than this k-tile's A1) is the same as with one epilogue block
+                if (after && more) stage_half(cur + SLOT_B1, p.W, b1_src, koff2);
+                if (after) finish_quarter(ptm, ptn, I1{}, I0{});
+            }
             if (more) {
-                stage_half(cur + SLOT_B1, p.W, b1_src, koff2);
+                if (!(kQuarters && after)) stage_half(cur + SLOT_B1, p.W, b1_src, koff2);
                 if (++c2_k == p.nk) { c2_k = 0; if (++c2_tile < my_count) { advance(c2m, c2n); set_c2(); } }
                 if (after && prev_full) {
                     if constexpr (kTileStores == 32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
@@ -1307,7 +1348,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         // After a tile's last phase row group 0 waits for row group 1, so that both run the
         // deferred epilogue at the same time (each hides the other's LDS and exchange latency)
         // instead of one after the other; group 1 falls half a phase behind again right after it.
-        if constexpr (kPiece) {
+        if constexpr (kPiece && !kQuarters) {
             if (wr == 0) TC_XBAR();
         }
         ptm = tm;
