@@ -153,7 +153,7 @@ def bench_train(args, world, rank, dev, dist_on, rccl_ranks=1):
         el = time.perf_counter() - t0
         if dist_on:
             dist.barrier()
-            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
         flat.grad_sync.enabled = True
@@ -188,11 +188,11 @@ def bench_train(args, world, rank, dev, dist_on, rccl_ranks=1):
             "config": {"workload": f"configs[3]: masked-LM optimiser step, {B} seqs x {T} tokens per GPU, 25 % "
                                    "positions selected (80/10/10) on the device each step, AdamW lr 2e-4 wd 0.1, gradient mean over ranks",
                        "seqs_per_gpu": B, "seq_len": T, "parallelism": f"data-parallel x{world}",
-                       "rccl_ranks": rccl_ranks,
+                       "rccl_ranks": rccl_ranks, "backend": args.backend if world > 1 else None,
                        "gradient_mean_bytes_per_step": int(flat.grad.numel()) * 4 if world > 1 else 0,
                        "exposed_communication_ms_per_step": exposed_ms,
                        "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3),
-                       "first_loss": round(float(losses[0]), 4), "last_loss": round(float(losses[-1]), 4)},
+                       "first_loss": round(float(losses[0].detach()), 4), "last_loss": round(float(losses[-1].detach()), 4)},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel / gemm_tn256x_kernel (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
@@ -271,7 +271,7 @@ def bench_varlen(args, world, rank, dev, dist_on, rccl_ranks=1):
         el = time.perf_counter() - t0
         if dist_on:
             dist.barrier()
-            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
         return el
@@ -301,7 +301,7 @@ def bench_varlen(args, world, rank, dev, dist_on, rccl_ranks=1):
                                    "without padding rows in batches of <= 131072 tokens, mean-pooled final states",
                        "n_seqs": n_total, "tokens": int(lens_all.sum()), "mean_len": round(float(lens_all.mean()), 1),
                        "batches_per_step_rank0": len(prepared), "parallelism": f"sequence-sharded x{world}",
-                       "rccl_ranks": rccl_ranks, "seqs_per_s": round(n_total * args.steps / elapsed, 1),
+                       "rccl_ranks": rccl_ranks, "backend": args.backend if world > 1 else None, "seqs_per_s": round(n_total * args.steps / elapsed, 1),
                        "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3)},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel / gemm256_kernel (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -414,6 +414,10 @@ def main():
     ap.add_argument("--train-seq-len", type=int, default=1024)
     ap.add_argument("--n-seqs", type=int, default=None,
                     help="config 3 / 5: total number of sequences (default 4096 / 100000)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend; gloo only to rehearse the multi-rank path on a box with one GPU")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal: every rank uses GPU 0 (RCCL refuses two ranks on one device, so use --backend gloo)")
     ap.add_argument("--dry-run", action="store_true",
                     help="print this rank's identity and exit before any GPU call (launcher test)")
     args = ap.parse_args()
@@ -432,13 +436,18 @@ def main():
                           "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
                           "config": args.config}), flush=True)
         return
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rccl_ranks = 1
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-        ones = torch.ones(1, device=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+        ones = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(ones)                      # the rank count RCCL itself sees
         rccl_ranks = int(ones.item())
         assert rccl_ranks == dist.get_world_size() == world
@@ -510,7 +519,7 @@ def main():
         el = time.perf_counter() - t0
         if dist_on:
             dist.barrier()
-            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
         return el, last
@@ -576,7 +585,7 @@ def main():
                        "seqs_per_gpu": n_seq, "seq_len": T, "micro_batch": B,
                        "codons_per_s": round(tokens_total / elapsed / 3, 1),
                        "weights": "random init N(0,0.02), 89.8M params", "parallelism": f"batch-sharded x{world}",
-                       "rccl_ranks": rccl_ranks,
+                       "rccl_ranks": rccl_ranks, "backend": args.backend if world > 1 else None,
                        "with_host_io_tokens_per_s": round(tokens_total / elapsed_io, 1),
                        "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3)},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel<bf16, EPI> (all GEMM launches of the step)",

@@ -95,6 +95,7 @@ class GradientSync:
         self.head_range = (0, starts[0])
         self.side = torch.cuda.Stream(device=store.grad.device) if store.grad.is_cuda else None
         self._pending = []
+        self._staged = False          # a bucket was exchanged synchronously through the host (gloo)
         self.error = None
 
     def world(self) -> int:
@@ -128,6 +129,13 @@ class GradientSync:
                 return
             b, e = self.head_range if layer < 0 else self.layer_ranges[layer]
             bucket = self.store.grad[b:e]
+            if bucket.is_cuda and dist.get_backend(self.group) == "gloo":
+                # gloo (rehearsals on a box with one GPU): staged through host memory, synchronously
+                host = bucket.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                bucket.copy_(host)
+                self._staged = True
+                return
             if bucket.is_cuda:
                 ready = torch.cuda.Event()
                 ready.record(torch.cuda.current_stream(bucket.device))
@@ -158,5 +166,6 @@ class GradientSync:
             work.wait()
         if err is not None:
             raise err
-        if pending:
+        if pending or self._staged:
             self.store.grad.div_(self.world())
+        self._staged = False
