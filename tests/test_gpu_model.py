@@ -198,8 +198,9 @@ def test_full_padded_batch(golden_dir, full_f32, full_bf16, dtype):
     _check(out["struct_label_output"].cpu().numpy(), g["struct"], keep, dtype)
 
 
+@pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("key", ["noutr", "utr"])
-def test_testcsv_f32_codon_agreement(golden_dir, full_f32, key):
+def test_testcsv_f32_codon_agreement(golden_dir, full_f32, key, packed):
     """cfg1: every bundled test.csv protein, without and with its 5'UTR, through the batched driver
     on the f32 path, against the RNA the reference's embed_sequence produced on the same weights.
     "Bit-exact except at ties": every codon that differs from the reference's must sit at a
@@ -215,7 +216,7 @@ def test_testcsv_f32_codon_agreement(golden_dir, full_f32, key):
         orgs.append(r["organism"])
         refs.append(rna)
         utrs.append(r["utr_seq"])
-    got = ta.optimize_codons(full_f32, prots, orgs, utrs if key == "utr" else None, max_batch_tokens=4096)
+    got = ta.optimize_codons(full_f32, prots, orgs, utrs if key == "utr" else None, max_batch_tokens=4096, packed=packed)
     total = diff = 0
     worst = 0.0
     for ri, (a, b) in enumerate(zip(got, refs)):
@@ -228,7 +229,7 @@ def test_testcsv_f32_codon_agreement(golden_dir, full_f32, key):
                 diff += 1
                 worst = max(worst, float(mg[i // 3]))
                 assert mg[i // 3] < MARGIN, (ri, i // 3, float(mg[i // 3]), a[i:i + 3], b[i:i + 3])
-    print(f"test.csv {key}: {diff} of {total} codons differ from the reference, all at margins <= {worst:.2e}")
+    print(f"test.csv {key} packed={packed}: {diff} of {total} codons differ from the reference, all at margins <= {worst:.2e}")
     assert total == sum(r["protein_len"] + 1 for r in meta)
     assert diff <= max(2, total // 1000), (diff, total)
 

@@ -168,12 +168,15 @@ def extract_embeddings(model, cds_seqs: Sequence[str], organisms: Sequence[Union
 
 def optimize_codons(model, proteins: Sequence[str], organisms: Sequence[Union[int, str]],
                     utrs: Optional[Sequence[str]] = None, max_batch_tokens: int = 1 << 17,
-                    max_aa: int = 2048) -> List[str]:
+                    max_aa: int = 2048, packed: bool = True) -> List[str]:
     """Batched codon optimisation: RNA string per protein (stop codon included).
 
     Proteins are given without the stop marker; like infer.py:262-269 a '_' is appended and
-    templates longer than 3*max_aa bases are truncated.  Sequences are sorted by length and
-    packed into padded batches of at most ``max_batch_tokens`` tokens."""
+    templates longer than 3*max_aa bases are truncated.  Sequences are sorted by length and run in
+    batches of at most ``max_batch_tokens`` tokens: packed=True lays a batch's sequences one after
+    the other without padding rows (ProteinBertModel.forward_packed), packed=False right-pads them
+    to the longest of the batch."""
+    import numpy as np
     dev = _model_device(model)
     items = []
     for i, prot in enumerate(proteins):
@@ -190,36 +193,46 @@ def optimize_codons(model, proteins: Sequence[str], organisms: Sequence[Union[in
     out: List[Optional[str]] = [None] * len(items)
     pos = 0
     while pos < len(order):
-        width = 0
+        width, ntok = 0, 0
         chunk = []
         while pos < len(order):
             cand = items[order[pos]]
             w = max(width, len(cand[1]))
-            if chunk and w * (len(chunk) + 1) > max_batch_tokens:
+            cost = ntok + len(cand[1]) if packed else w * (len(chunk) + 1)
+            if chunk and cost > max_batch_tokens:
                 break
             chunk.append(cand)
             width = w
+            ntok += len(cand[1])
             pos += 1
         B = len(chunk)
-        tok = torch.full((B, width), _ALPHABET.padding_idx, dtype=torch.int32)
-        for r, (_, ids, _, _, _) in enumerate(chunk):
-            tok[r, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
-        species = torch.tensor([c[4] for c in chunk], dtype=torch.int32)
         aa_all = b"".join(ops.encode_amino_acids(c[3]) for c in chunk)
         offs = [0]
         for c in chunk:
             offs.append(offs[-1] + len(c[3]))
-        row0 = [r * width + c[2] for r, c in enumerate(chunk)]
-        with torch.no_grad():
-            logits = model(tok.to(dev), species.to(dev))["logits"]
+        if packed:
+            cu = np.concatenate([[0], np.cumsum([len(c[1]) for c in chunk])])
+            flat = torch.from_numpy(np.concatenate([np.asarray(c[1], np.int32) for c in chunk]))
+            row0 = [int(cu[r]) + c[2] for r, c in enumerate(chunk)]
+            with torch.no_grad():
+                logits = model.forward_packed(flat.to(dev), [c[4] for c in chunk], cu, want_struct=False,
+                                              want_representation=False)["logits"]
+        else:
+            tok = torch.full((B, width), _ALPHABET.padding_idx, dtype=torch.int32)
+            for r, (_, ids, _, _, _) in enumerate(chunk):
+                tok[r, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+            species = torch.tensor([c[4] for c in chunk], dtype=torch.int32)
+            row0 = [r * width + c[2] for r, c in enumerate(chunk)]
+            with torch.no_grad():
+                logits = model(tok.to(dev), species.to(dev))["logits"].view(B * width, -1)
         bases = ops.codon_decode(
-            logits.view(B * width, -1),
+            logits,
             torch.frombuffer(bytearray(aa_all), dtype=torch.uint8).to(dev),
             torch.tensor(offs, dtype=torch.int32, device=dev),
             torch.tensor(row0, dtype=torch.int32, device=dev))
-        flat = bytes(bases.cpu().numpy()).decode("ascii")
+        flat_s = bytes(bases.cpu().numpy()).decode("ascii")
         for r, c in enumerate(chunk):
-            rna = flat[3 * offs[r]:3 * offs[r + 1]]
+            rna = flat_s[3 * offs[r]:3 * offs[r + 1]]
             if not back_translation_ok(rna, c[3]):
                 raise RuntimeError(f"prediction for sequence {c[0]} does not translate back to its protein")
             out[c[0]] = rna
