@@ -84,10 +84,21 @@ bool tc_prof_launch_events(hipEvent_t *start, hipEvent_t *stop);
 #endif
 
 // ---- device helpers ---------------------------------------------------------------
+// Sum over the 64 lanes on the VALU's lane crossbar (DPP) instead of six trips through the LDS
+// permute network: quad, half-row and row mirrors leave every lane of a 16-lane row with the row
+// sum, two row broadcasts fold the four rows into lane 63, and a lane read returns it to all.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float tc_dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float tc_wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += tc_dpp_f32<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v += tc_dpp_f32<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+    v += tc_dpp_f32<0x141, 0xf>(v);     // row_half_mirror
+    v += tc_dpp_f32<0x140, 0xf>(v);     // row_mirror
+    v += tc_dpp_f32<0x142, 0xa>(v);     // row_bcast15 into rows 1 and 3
+    v += tc_dpp_f32<0x143, 0xc>(v);     // row_bcast31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float tc_wave_max(float v) {
 #pragma unroll

@@ -2,6 +2,7 @@
 // One 64-lane wave owns one row; lanes read 16 bytes at a time; reductions are
 // wave-wide shuffles, no LDS.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -201,8 +202,20 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const T *__restrict__ g,
             wreg[o][c] = ok ? *reinterpret_cast<const f32x4 *>(W + (long)o * E + col) : f32x4{0, 0, 0, 0};
     }
     const float my_bias = lane < V ? bias[lane] : 0.f;
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
-        const T *src = g + (long)row * ldg + col0;
+    // The next row's loads are issued before this row's arithmetic, so their latency is covered
+    // by the V + 2 reductions instead of being paid once per row.
+    using Raw = typename std::conditional<sizeof(T) == 2, u32x2, f32x4>::type;
+    Raw raw[NCH];
+    const int stride = gridDim.x * 4;
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row < M) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < E) raw[c] = *reinterpret_cast<const Raw *>(g + (long)row * ldg + col0 + col);
+        }
+    }
+    for (; row < M; row += stride) {
         f32x4 v[NCH];
         float s = 0.f;
 #pragma unroll
@@ -210,15 +223,21 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const T *__restrict__ g,
             const int col = c * 256 + lane * 4;
             if (col < E) {
                 if constexpr (sizeof(T) == 2) {
-                    const u32x2 w = *reinterpret_cast<const u32x2 *>(src + col);
-                    v[c] = f32x4{tc_bf16_lo(w[0]), tc_bf16_hi(w[0]), tc_bf16_lo(w[1]), tc_bf16_hi(w[1])};
+                    v[c] = f32x4{tc_bf16_lo(raw[c][0]), tc_bf16_hi(raw[c][0]), tc_bf16_lo(raw[c][1]), tc_bf16_hi(raw[c][1])};
                 } else {
-                    v[c] = *reinterpret_cast<const f32x4 *>(src + col);
+                    v[c] = raw[c];
                 }
             } else {
                 v[c] = f32x4{0, 0, 0, 0};
             }
             s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        }
+        if (row + stride < M) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int col = c * 256 + lane * 4;
+                if (col < E) raw[c] = *reinterpret_cast<const Raw *>(g + (long)(row + stride) * ldg + col0 + col);
+            }
         }
         const float mean = tc_wave_sum(s) / (float)E;
         float q = 0.f;

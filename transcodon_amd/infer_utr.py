@@ -64,6 +64,27 @@ def _model_device(model):
     return next(model.parameters()).device
 
 
+class _HostCheckedIds:
+    """Inside the batched drivers the token ids come from this module's tokeniser and the species ids
+    are checked here on the host, so the per-forward device-side range check (one host
+    synchronisation per forward) is switched off for the duration."""
+
+    def __init__(self, model, species):
+        self.model = model
+        n = getattr(getattr(model, "args", None), "species_vocab_size", None)
+        if n is not None and any(not (0 <= int(s) < n) for s in species):
+            raise IndexError("species id out of range")
+
+    def __enter__(self):
+        self.prev = getattr(self.model, "check_indices", None)
+        if self.prev is not None:
+            self.model.check_indices = False
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            self.model.check_indices = self.prev
+
+
 def embed_sequence(model, utr_seq, sequence: Union[str, WithUtr_CodonSequence_infer],
                    species_type_ids: Union[int, str] = 0, AA_seq: str = "", average: bool = True):
     """Returns (representations, logits sliced to the CDS [1, 3m(+), vocab], predicted RNA)."""
@@ -113,6 +134,11 @@ def extract_embeddings(model, cds_seqs: Sequence[str], organisms: Sequence[Union
     enc = [_ALPHABET.encode(CodonSequence("", s).seq)[:max_positions] for s in cds_seqs]
     species = [_species_id(o) for o in organisms]
     out = [None] * len(enc)
+    with _HostCheckedIds(model, species):
+        return _extract(model, enc, species, out, dev, L, max_batch_tokens, pooled, packed)
+
+
+def _extract(model, enc, species, out, dev, L, max_batch_tokens, pooled, packed):
     if packed:
         import numpy as np
         pos = 0
@@ -189,6 +215,12 @@ def optimize_codons(model, proteins: Sequence[str], organisms: Sequence[Union[in
         ids = _ALPHABET.encode(seq.seq)
         start = 1 + (0 if utr is None else len(utr.replace(" ", "")) + 1)
         items.append((i, ids, start, aa, _species_id(organisms[i])))
+    with _HostCheckedIds(model, [it[4] for it in items]):
+        return _optimize(model, items, dev, max_batch_tokens, packed)
+
+
+def _optimize(model, items, dev, max_batch_tokens, packed):
+    import numpy as np
     order = sorted(range(len(items)), key=lambda k: len(items[k][1]))
     out: List[Optional[str]] = [None] * len(items)
     pos = 0
