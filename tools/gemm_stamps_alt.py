@@ -15,6 +15,9 @@ lib.tc_gemm.restype = C.c_int
 lib.tc_gemm.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                         C.c_float, vp, vp, C.c_int, C.c_int, vp]
 lib.tc_debug_set_stamp_buffer.argtypes = [vp]
+lib.tc_last_error.restype = C.c_char_p
+lib.tc_gemm_train.restype = C.c_int
+lib.tc_gemm_train.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
 
 dev = "cuda"
 M, E, F, T = 131072, 768, 3072, 512
@@ -26,17 +29,25 @@ ang = torch.arange(T, dtype=torch.float32)[:, None] * (1.0 / 10000 ** (torch.ara
 cos, sin = ang.cos().to(dev).contiguous(), ang.sin().to(dev).contiguous()
 stamps = torch.zeros(256 * 2 * 32 + 256 * 2 * 26, dtype=torch.int64, device=dev)
 lib.tc_debug_set_stamp_buffer(stamps.data_ptr())
-for name, a, N, K, epi in (("bias", x, F, E, 0), ("fc1", x, F, E, 1), ("qkv", x, 3 * E, E, 3), ("out", x, E, E, 2)):
+SHAPES = {"bias": (x, F, E, 0), "fc1": (x, F, E, 1), "qkv": (x, 3 * E, E, 3), "out": (x, E, E, 2),
+          "out_f32": (x, E, E, 4), "out_bf16": (x, E, E, 0),
+          "fc2": (mid, E, F, 2), "fc2_f32": (mid, E, F, 4), "fc2_bf16": (mid, E, F, 0)}
+names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["bias", "fc1", "qkv", "out"]
+for name in names:
+    a, N, K, epi = SHAPES[name]
     w = (torch.randn(N, K, device=dev, generator=g) * 0.03).bfloat16()
     b = torch.randn(N, device=dev, generator=g) * 0.1
     ldo = N + 64 if N == F else N      # rows of 6144 bytes store slowly: pad them
-    out = torch.empty(M, ldo, device=dev, dtype=torch.float32 if epi == 2 else torch.bfloat16)
+    out = torch.empty(M, ldo, device=dev, dtype=torch.float32 if epi in (2, 4) else torch.bfloat16)
     s = torch.cuda.current_stream().cuda_stream
     for it in range(3):
         stamps.zero_()
-        rc = lib.tc_gemm(1, epi, a.data_ptr(), K, w.data_ptr(), b.data_ptr(), res.data_ptr() if epi == 2 else None,
-                         out.data_ptr(), ldo, M, N, K, 0.125, cos.data_ptr(), sin.data_ptr(), T, 64, s)
-        assert rc == 0
+        if epi == 4:
+            rc = lib.tc_gemm_train(1, 4, a.data_ptr(), a.shape[1], w.data_ptr(), None, None, out.data_ptr(), None, ldo, M, N, K, 1, s)
+        else:
+            rc = lib.tc_gemm(1, epi, a.data_ptr(), a.shape[1], w.data_ptr(), None if epi == 4 else b.data_ptr(), res.data_ptr() if epi == 2 else None,
+                             out.data_ptr(), ldo, M, N, K, 0.125, cos.data_ptr(), sin.data_ptr(), T, 64, s)
+        assert rc == 0, lib.tc_last_error()
     torch.cuda.synchronize()
     st = stamps[:256 * 2 * 32].view(256, 2, 32).double().cpu()
     ph = stamps[256 * 2 * 32:].view(256, 2, 2, 13).double().cpu()
