@@ -124,15 +124,26 @@ def bench_train(args, world, rank, dev, dist_on, rccl_ranks=1):
     tok_clean, sp = torch.from_numpy(tok_np).to(dev), torch.from_numpy(sp_np).to(dev)
     lens = torch.full((B,), T, dtype=torch.int32, device=dev)
     losses = []
+    struct = None
+    if args.struct_labels:
+        # the variant with '.()' structure labels on half of the positions: the 0.4-weighted second
+        # cross-entropy term (pretraining.py:117-126) and the structure head's backward run as well
+        st_np = np.where(rng.random((B, T)) < 0.5, rng.integers(0, 3, (B, T)), -100)
+        struct = torch.from_numpy(st_np).to(dev)
+    with_opt = [True]
 
     def step(i):
         # fresh corruption of the clean batch every step, on the device (the collator's job)
         tok, labels, _ = TR.mlm_mask(tok_clean, lens, seed=(1236 + rank) * 1000003 + i)
         flat.zero_grad()
         out = model(tok, sp)
-        loss = TR.mlm_loss(out["logits"], labels)        # structure labels are all -100 as shipped
+        if struct is None:
+            loss = TR.mlm_loss(out["logits"], labels)    # structure labels are all -100 as shipped
+        else:
+            loss = TR.mlm_loss(out["logits"], labels, out["struct_label_output"], struct)
         loss.backward()                                  # includes the gradient mean over ranks
-        opt.step(lr_factor=TR.warmup_cosine(i, 100, 10000), exclude=struct_params)
+        if with_opt[0]:
+            opt.step(lr_factor=TR.warmup_cosine(i, 100, 10000), exclude=() if struct is not None else struct_params)
         return loss
 
     lib = _lib.load()
@@ -167,10 +178,13 @@ def bench_train(args, world, rank, dev, dist_on, rccl_ranks=1):
     lib.tc_prof_enable(0)
     n, ms, flops = _lib.prof_collect(_lib.PROF_GEMM)
     an, ams, aflops = _lib.prof_collect(_lib.PROF_ATTN)
+    with_opt[0] = False                                         # forward + loss + backward only
+    elapsed_noopt, _ = timed(args.warmup + 2 * args.steps)
+    with_opt[0] = True
     exposed_ms = None
     if dist_on:
         # the same steps without the gradient exchange (ranks drift apart: timing only, run last)
-        elapsed_local, _ = timed(args.warmup + 2 * args.steps, sync_grads=False)
+        elapsed_local, _ = timed(args.warmup + 3 * args.steps, sync_grads=False)
         exposed_ms = round(1e3 * (elapsed - elapsed_local) / args.steps, 3)
     if rank == 0:
         tokens_total = world * B * T * args.steps
@@ -192,6 +206,8 @@ def bench_train(args, world, rank, dev, dist_on, rccl_ranks=1):
                        "gradient_mean_bytes_per_step": int(flat.grad.numel()) * 4 if world > 1 else 0,
                        "exposed_communication_ms_per_step": exposed_ms,
                        "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3),
+                       "without_adamw_ms_per_step": round(1e3 * elapsed_noopt / args.steps, 3),
+                       "structure_labels": bool(args.struct_labels),
                        "first_loss": round(float(losses[0].detach()), 4), "last_loss": round(float(losses[-1].detach()), 4)},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel / gemm_tn256x_kernel (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -412,6 +428,8 @@ def main():
                     help="train = --config 4 (kept for older command lines)")
     ap.add_argument("--train-batch", type=int, default=64)
     ap.add_argument("--train-seq-len", type=int, default=1024)
+    ap.add_argument("--struct-labels", action="store_true",
+                    help="config 4 with structure labels on half of the positions (the 0.4-weighted second loss term)")
     ap.add_argument("--n-seqs", type=int, default=None,
                     help="config 3 / 5: total number of sequences (default 4096 / 100000)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
