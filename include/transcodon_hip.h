@@ -325,6 +325,50 @@ int tc_attn_bwd_static(int dtype, const void *qkv, int ldq, const uint64_t *key_
                        const void *d_out, const float *lse, void *d_qkv, int ldg, const float *rope_cos,
                        const float *rope_sin, float q_scale, int B, int T, int H, int D, void *stream);
 
+/* ---- LayerNorm folded into the products on either side of it (bf16, large batches) ----- */
+/*
+ * transcodon/modules.py:87,100: h = LayerNorm(x) feeds a Linear layer (q/k/v at :88-95 through
+ * multihead_attention.py:260-262, fc1 at :101), and x itself is the result of the Linear layer +
+ * residual add before it (:96-97 out_proj, :102-104 fc2).  With xb = bf16(x), mean / rstd of xb's row,
+ *     Linear(LayerNorm(xb))[n] = rstd * sum_k xb[k] (gamma o W)[n,k] - rstd * mean * s[n] + c[n],
+ *     s[n] = sum_k (gamma o W)[n,k],   c[n] = sum_k beta[k] W[n,k] + b[n],
+ * so the normalised activations never exist in memory: the residual product writes xb and the row sums
+ * next to x, the next product multiplies xb by gamma o W and its epilogue applies the rest.  The
+ * LayerNorm input is rounded to bf16 (the separate kernel rounds its output instead); everything
+ * else is f32.  Only the large-tile bf16 kernels have these epilogues: ask tc_ln_fold_supported.
+ *
+ * tc_ln_fold_weights   W f32 [N,K], gamma/beta f32 [K], bias f32 [N] or NULL -> Wf bf16 [N,K] =
+ *                      bf16(gamma o W), s f32 [N] (sums of the ROUNDED Wf rows), c f32 [N].
+ * tc_embed_fwd_ln      tc_embed_fwd that also writes xb bf16 [B*T,E] and ln_rows f32 [B*T,2] =
+ *                      (rstd, -rstd * mean) of xb's rows.
+ * tc_gemm_residual_ln  tc_gemm(TC_EPI_BIAS_RESIDUAL) that also writes out_bf16 [M,ldo] = bf16(out) and
+ *                      adds, per row, the sum and the sum of squares of the bf16-rounded results to
+ *                      row_acc (uint64 [rows,2], two's-complement integers in units of 2^-24: integer
+ *                      adds, so the result does not depend on the order of the column tiles).  row_acc
+ *                      must be zero before the call.
+ * tc_ln_rows_finalize  row_acc -> ln_rows f32 [M,2] = (rstd, -rstd * mean) over E columns, in double
+ *                      precision; clears row_acc for the next product.
+ * tc_gemm_ln           tc_gemm(TC_EPI_QKV_ROPE or TC_EPI_BIAS_GELU) on A = xb with Wf, c, s and ln_rows.
+ *                      ln_rows must be readable up to the next multiple of 256 rows.
+ * tc_ln_fold_supported 1 if a forward of B x T tokens with widths E, F runs all its products on the
+ *                      kernels that have these epilogues (then tc_encoder_forward folds when the
+ *                      descriptor's layers carry the folded weights), else 0.
+ */
+int tc_ln_fold_weights(const float *W, const float *gamma, const float *beta, const float *bias, void *Wf,
+                       float *s_out, float *c_out, int N, int K, void *stream);
+int tc_embed_fwd_ln(const int32_t *tokens, const int32_t *species, const float *tok_table,
+                    const float *species_table, float *x, uint8_t *pad_flags, int32_t *bad_index, int B, int T,
+                    int E, int vocab, int n_species, int pad_idx, void *xb, float *ln_rows, float eps,
+                    void *stream);
+int tc_gemm_residual_ln(int dtype, const void *A, int lda, const void *W, const float *bias, const float *residual,
+                        void *out, void *out_bf16, unsigned long long *row_acc, int ldo, int M, int N, int K,
+                        void *stream);
+int tc_ln_rows_finalize(unsigned long long *row_acc, float *ln_rows, int M, int E, float eps, void *stream);
+int tc_gemm_ln(int dtype, int epilogue, const void *A, int lda, const void *Wf, const float *c, const float *s,
+               const float *ln_rows, void *out, int ldo, int M, int N, int K, float q_scale, const float *rope_cos,
+               const float *rope_sin, int T, int head_dim, void *stream);
+int tc_ln_fold_supported(int dtype, int B, int T, int E, int F);
+
 /* ---- whole-encoder convenience (one call per forward) ---------------------------- */
 
 typedef struct tc_layer_weights {
@@ -339,6 +383,14 @@ typedef struct tc_layer_weights {
     const void *w_fc2;            /* [E,F]                                            */
     const float *b_fc2;
     const float *rope_cos, *rope_sin; /* f32 [T_table, D/2] for this layer's rope.freqs */
+    /* Optional (all six or none, bf16 only): the two LayerNorms folded into the products that follow
+     * them, as tc_ln_fold_weights makes them from (w_qkv, ln1_g, ln1_b, b_qkv) and (w_fc1, ln2_g,
+     * ln2_b, b_fc1).  When every layer has them and tc_ln_fold_supported says so, tc_encoder_forward
+     * runs no LayerNorm kernel inside the layers. */
+    const void *w_qkv_ln;         /* [3E,E] bf16(gamma1 o W)                          */
+    const float *c_qkv_ln, *s_qkv_ln; /* [3E] beta1 W^T + b;  row sums of w_qkv_ln     */
+    const void *w_fc1_ln;         /* [F,E]                                            */
+    const float *c_fc1_ln, *s_fc1_ln;
 } tc_layer_weights;
 
 typedef struct tc_encoder_desc {

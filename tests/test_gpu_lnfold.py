@@ -1,0 +1,186 @@
+"""LayerNorm folded into the products on either side of it (tc_gemm_residual_ln, tc_ln_rows_finalize,
+tc_gemm_ln, tc_ln_fold_weights, tc_embed_fwd_ln) through the C ABI against plain fp32 torch.
+
+The folded form computes Linear(LayerNorm(bf16(x))) with bf16(gamma o W); the separate kernels compute
+Linear(bf16(LayerNorm(x))) with bf16(W).  Both are compared with the same fp64 reference of the fp32
+graph (modules.py:87-101); stated tolerance for either: |error| <= 0.02 + 1 % (bf16 operands over
+K = 768), and the folded form may not be further from the reference than 1.5x the separate form."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import transcodon_ref as O
+from transcodon_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+M, E, F, T = 32768, 768, 3072, 512
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _inputs(seed, row_mean=0.5):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, E, generator=g) * (0.5 + torch.rand(E, generator=g)) + row_mean * torch.randn(1, E, generator=g)
+    x[:, 7] *= 20.0                                   # an outlier channel, as residual streams have
+    x[5] = 0.0                                        # an all-zero (padding) row
+    gamma = 1 + 0.1 * torch.randn(E, generator=g)
+    beta = 0.1 * torch.randn(E, generator=g)
+    return x, gamma, beta, g
+
+
+def _fold(lib, W, gamma, beta, bias):
+    N, K = W.shape
+    wf = torch.empty(N, K, dtype=torch.bfloat16, device=DEV)
+    s = torch.empty(N, device=DEV)
+    c = torch.empty(N, device=DEV)
+    _lib.check(lib.tc_ln_fold_weights(W.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bias.data_ptr(), wf.data_ptr(),
+                                      s.data_ptr(), c.data_ptr(), N, K, _stream()), "tc_ln_fold_weights")
+    return wf, s, c
+
+
+def test_fold_weights_match_their_definition():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    W = (torch.randn(F, E, generator=g) * 0.02).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(E, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(E, generator=g)).to(DEV)
+    bias = (0.02 * torch.randn(F, generator=g)).to(DEV)
+    wf, s, c = _fold(lib, W, gamma, beta, bias)
+    ref_wf = (W * gamma[None, :]).to(torch.bfloat16)
+    assert torch.equal(wf, ref_wf)
+    np.testing.assert_allclose(s.cpu().numpy(), ref_wf.double().sum(1).cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(c.cpu().numpy(), (W.double() @ beta.double() + bias.double()).cpu().numpy(), rtol=0, atol=2e-6)
+
+
+def _residual_ln(lib, a, w, bias, res, K):
+    out = torch.empty(M, E, device=DEV)
+    outb = torch.empty(M, E, dtype=torch.bfloat16, device=DEV)
+    acc = torch.zeros(M, 2, dtype=torch.int64, device=DEV)
+    _lib.check(lib.tc_gemm_residual_ln(_lib.TC_BF16, a.data_ptr(), a.shape[1], w.data_ptr(), bias.data_ptr(),
+                                       res.data_ptr(), out.data_ptr(), outb.data_ptr(), acc.data_ptr(), E, M, E, K,
+                                       _stream()), "tc_gemm_residual_ln")
+    return out, outb, acc
+
+
+def test_residual_product_writes_copy_and_row_sums():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, E, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(E, E, generator=g) * 0.03).to(DEV, torch.bfloat16)
+    bias = (0.1 * torch.randn(E, generator=g)).to(DEV)
+    res = (torch.randn(M, E, generator=g) * 3 + 1.0).to(DEV)
+    plain = ops.gemm(a, w, bias, epilogue=_lib.EPI_BIAS_RESIDUAL, residual=res)
+    out, outb, acc = _residual_ln(lib, a, w, bias, res, E)
+    assert torch.equal(out, plain)                                    # the f32 result is the unfolded kernel's
+    assert torch.equal(outb, out.to(torch.bfloat16))
+    xb = outb.double()
+    s1 = acc[:, 0].double() / 2 ** 24
+    s2 = acc[:, 1].double() / 2 ** 24
+    np.testing.assert_allclose(s1.cpu().numpy(), xb.sum(1).cpu().numpy(), rtol=0, atol=2e-3)
+    np.testing.assert_allclose(s2.cpu().numpy(), (xb * xb).sum(1).cpu().numpy(), rtol=3e-6)
+    # integer accumulation: a second run gives the same bits
+    _, _, acc2 = _residual_ln(lib, a, w, bias, res, E)
+    assert torch.equal(acc, acc2)
+    rows = torch.empty(M, 2, device=DEV)
+    _lib.check(lib.tc_ln_rows_finalize(acc.data_ptr(), rows.data_ptr(), M, E, 1e-5, _stream()), "tc_ln_rows_finalize")
+    assert int(acc.abs().max()) == 0                                   # cleared for the next product
+    mean = xb.mean(1)
+    rstd = 1.0 / torch.sqrt(xb.var(1, unbiased=False) + 1e-5)
+    np.testing.assert_allclose(rows[:, 0].cpu().numpy(), rstd.cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(rows[:, 1].cpu().numpy(), (-rstd * mean).cpu().numpy(), rtol=2e-5, atol=1e-6)
+
+
+def _rows_of(xb):
+    x = xb.double()
+    rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)
+    rows = torch.zeros((M + 255) // 256 * 256, 2, device=DEV)
+    rows[:M, 0] = rstd.float()
+    rows[:M, 1] = (-rstd * x.mean(1)).float()
+    return rows
+
+
+@pytest.mark.parametrize("epi", ["gelu", "qkv"])
+def test_folded_product_against_fp64_reference(epi):
+    lib = _lib.load()
+    x, gamma, beta, g = _inputs(11)
+    N = F if epi == "gelu" else 3 * E
+    W = torch.randn(N, E, generator=g) * 0.02
+    bias = 0.02 * torch.randn(N, generator=g)
+    # fp64 reference of LayerNorm -> Linear (-> GELU | q scale + rotary)
+    xd = x.double()
+    h = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-5) * gamma.double() + beta.double()
+    y = h @ W.double().t() + bias.double()
+    ang = torch.arange(T, dtype=torch.float32)[:, None] * O.rope_freqs(64).float()[None, :]
+    cos, sin = ang.cos(), ang.sin()
+    if epi == "gelu":
+        ref = torch.nn.functional.gelu(y)
+    else:
+        y3 = y.view(M // T, T, 3, E // 64, 64).clone()
+        y3[:, :, 0] *= 0.125
+        for sec in (0, 1):
+            v = y3[:, :, sec]
+            a, b = v[..., 0::2].clone(), v[..., 1::2].clone()
+            c, s_ = cos.double()[None, :, None, :], sin.double()[None, :, None, :]
+            v[..., 0::2] = a * c - b * s_
+            v[..., 1::2] = b * c + a * s_
+        ref = y3.reshape(M, 3 * E)
+    xg, Wg, gg, bg, biasg = x.to(DEV), W.to(DEV), gamma.to(DEV), beta.to(DEV), bias.to(DEV)
+    cosg, sing = cos.to(DEV).contiguous(), sin.to(DEV).contiguous()
+    # separate kernels
+    hsep = ops.layernorm(xg, gg, bg, 1e-5, torch.bfloat16)
+    if epi == "gelu":
+        sep = ops.gemm(hsep, Wg.to(torch.bfloat16), biasg, epilogue=_lib.EPI_BIAS_GELU)
+    else:
+        sep = ops.gemm(hsep, Wg.to(torch.bfloat16), biasg, epilogue=_lib.EPI_QKV_ROPE, q_scale=0.125, rope_cos=cosg,
+                       rope_sin=sing, T=T, head_dim=64)
+    # folded
+    wf, s, c = _fold(lib, Wg, gg, bg, biasg)
+    xb = xg.to(torch.bfloat16)
+    rows = _rows_of(xb)
+    ldo = N + 64 if epi == "gelu" else N
+    out = torch.empty(M, ldo, dtype=torch.bfloat16, device=DEV)
+    code = _lib.EPI_BIAS_GELU if epi == "gelu" else _lib.EPI_QKV_ROPE
+    _lib.check(lib.tc_gemm_ln(_lib.TC_BF16, code, xb.data_ptr(), E, wf.data_ptr(), c.data_ptr(), s.data_ptr(),
+                              rows.data_ptr(), out.data_ptr(), ldo, M, N, E, 0.125, cosg.data_ptr(), sing.data_ptr(),
+                              T, 64, _stream()), "tc_gemm_ln")
+    torch.cuda.synchronize()
+    fold = out[:, :N].double().cpu()
+    sep = sep[:, :N].double().cpu()
+    tol = 0.02 + 0.01 * ref.abs()
+    e_fold, e_sep = (fold - ref).abs(), (sep - ref).abs()
+    assert bool((e_fold <= tol).all()), float((e_fold - tol).max())
+    assert bool((e_sep <= tol).all()), float((e_sep - tol).max())
+    rms_f, rms_s = float(e_fold.pow(2).mean().sqrt()), float(e_sep.pow(2).mean().sqrt())
+    print(f"\n{epi}: rms error folded {rms_f:.3e}, separate kernels {rms_s:.3e}")
+    assert rms_f <= 1.5 * rms_s
+    # the padding row: LayerNorm of zeros is beta
+    np.testing.assert_allclose(fold[5].numpy(), ref[5].numpy(), atol=0.02)
+
+
+def test_embed_with_row_statistics():
+    lib = _lib.load()
+    B, Tn = 8, 64
+    g = torch.Generator().manual_seed(2)
+    tok = torch.randint(0, 10, (B, Tn), generator=g, dtype=torch.int32)
+    tok[1, 40:] = 1
+    sp = torch.randint(0, 16, (B,), generator=g, dtype=torch.int32)
+    tt = torch.randn(10, E, generator=g).to(DEV)
+    st = torch.randn(16, E, generator=g).to(DEV)
+    x = torch.empty(B * Tn, E, device=DEV)
+    xb = torch.empty(B * Tn, E, dtype=torch.bfloat16, device=DEV)
+    rows = torch.empty(B * Tn, 2, device=DEV)
+    pad = torch.empty(B * Tn, dtype=torch.uint8, device=DEV)
+    tok_d, sp_d = tok.to(DEV), sp.to(DEV)
+    _lib.check(lib.tc_embed_fwd_ln(tok_d.data_ptr(), sp_d.data_ptr(), tt.data_ptr(), st.data_ptr(),
+                                   x.data_ptr(), pad.data_ptr(), None, B, Tn, E, 10, 16, 1, xb.data_ptr(),
+                                   rows.data_ptr(), 1e-5, _stream()), "tc_embed_fwd_ln")
+    ref = (tt[tok.long().to(DEV)] + st[sp.long().to(DEV)][:, None, :]) * (tok.to(DEV) != 1)[..., None]
+    assert torch.equal(x.view(B, Tn, E), ref)
+    assert torch.equal(xb, x.to(torch.bfloat16))
+    v = xb.double()
+    rstd = 1.0 / torch.sqrt(v.var(1, unbiased=False) + 1e-5)
+    np.testing.assert_allclose(rows[:, 0].cpu().numpy(), rstd.cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(rows[:, 1].cpu().numpy(), (-rstd * v.mean(1)).cpu().numpy(), rtol=2e-5, atol=1e-6)

@@ -25,6 +25,9 @@ def load(path):
     res, args = _lib._SIGNATURES["tc_gemm"]
     lib.tc_gemm.restype, lib.tc_gemm.argtypes = res, args
     lib.tc_last_error.restype = C.c_char_p
+    if hasattr(lib, "tc_gemm_residual_ln"):
+        res, args = _lib._SIGNATURES["tc_gemm_residual_ln"]
+        lib.tc_gemm_residual_ln.restype, lib.tc_gemm_residual_ln.argtypes = res, args
     return lib
 
 
@@ -53,7 +56,12 @@ def main():
               "out": (x, E, E, E, _lib.EPI_BIAS_RESIDUAL, E, True),
               "fc1": (x, E, F, E, _lib.EPI_BIAS_GELU, F + 64, False),
               "fc1_bias": (x, E, F, E, _lib.EPI_BIAS, F + 64, False),
-              "fc2": (mid, F + 64, E, F, _lib.EPI_BIAS_RESIDUAL, E, True)}
+              "fc2": (mid, F + 64, E, F, _lib.EPI_BIAS_RESIDUAL, E, True),
+              # the new build also writes the bf16 copy and the row sums of a folded LayerNorm
+              "out_ln": (x, E, E, E, _lib.EPI_BIAS_RESIDUAL, E, True),
+              "fc2_ln": (mid, F + 64, E, F, _lib.EPI_BIAS_RESIDUAL, E, True)}
+    copy16 = torch.empty(M, E, device=dev, dtype=torch.bfloat16)
+    row_acc = torch.zeros(M, 2, device=dev, dtype=torch.int64)
     for name in a.only.split(","):
         A, lda, N, K, epi, ldo, f32 = shapes[name]
         w = (torch.randn(N, K, device=dev, generator=g) * 0.03).bfloat16()
@@ -61,6 +69,11 @@ def main():
         outs = {k: torch.zeros(M, ldo, device=dev, dtype=torch.float32 if f32 else torch.bfloat16) for k in libs}
 
         def run(k):
+            if name.endswith("_ln") and k == "new":
+                rc = libs[k].tc_gemm_residual_ln(1, A.data_ptr(), lda, w.data_ptr(), b.data_ptr(), res.data_ptr(),
+                                                 outs[k].data_ptr(), copy16.data_ptr(), row_acc.data_ptr(), ldo, M, N, K, strm)
+                assert rc == 0, libs[k].tc_last_error()
+                return
             rc = libs[k].tc_gemm(1, epi, A.data_ptr(), lda, w.data_ptr(), b.data_ptr(), res.data_ptr() if f32 else None,
                                  outs[k].data_ptr(), ldo, M, N, K, 0.125, cos.data_ptr(), sin.data_ptr(), T, 64, strm)
             assert rc == 0, libs[k].tc_last_error()

@@ -22,7 +22,8 @@ vp = C.c_void_p
 class LayerWeights(C.Structure):
     _fields_ = [(n, vp) for n in (
         "ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_g", "ln2_b",
-        "w_fc1", "b_fc1", "w_fc2", "b_fc2", "rope_cos", "rope_sin")]
+        "w_fc1", "b_fc1", "w_fc2", "b_fc2", "rope_cos", "rope_sin",
+        "w_qkv_ln", "c_qkv_ln", "s_qkv_ln", "w_fc1_ln", "c_fc1_ln", "s_fc1_ln")]
 
 
 class EncoderDesc(C.Structure):
@@ -64,6 +65,14 @@ _SIGNATURES = {
     "tc_version": (C.c_int, []),
     "tc_last_error": (C.c_char_p, []),
     "tc_embed_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
+    "tc_embed_fwd_ln": (C.c_int, [vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 6 + [vp, vp, C.c_float, vp]),
+    "tc_ln_rows_finalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
+    "tc_ln_fold_weights": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "tc_gemm_ln": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_float, vp, vp, C.c_int, C.c_int, vp]),
+    "tc_gemm_residual_ln": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, vp]),
+    "tc_ln_fold_supported": (C.c_int, [C.c_int] * 5),
     "tc_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "tc_gemm": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
                           C.c_int, C.c_int, C.c_float, vp, vp, C.c_int, C.c_int, vp]),

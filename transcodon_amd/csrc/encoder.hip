@@ -13,6 +13,12 @@ struct Workspace {
     int ld_mid;
     uint8_t *pad;      // [M]
     uint64_t *words;   // [B, ceil(T/64)]
+    // LayerNorms folded into the products (bf16 only): bf16 copy of the residual stream, per row
+    // (rstd, -rstd * mean) and the integer accumulators they are made from, rows rounded up to 256
+    void *xb;
+    float *ln_rows;
+    unsigned long long *row_acc;
+    size_t rows_pad;
     size_t total;
 };
 
@@ -37,6 +43,12 @@ Workspace carve(const tc_encoder_desc *d, int B, int T, char *base) {
     w.mid = take(M * (size_t)w.ld_mid * esz);
     w.pad = reinterpret_cast<uint8_t *>(take(M));
     w.words = reinterpret_cast<uint64_t *>(take((size_t)B * ((T + 63) / 64) * 8));
+    if (d->dtype == TC_BF16) {
+        w.rows_pad = (M + 255) / 256 * 256;
+        w.xb = take(M * d->E * 2);
+        w.ln_rows = reinterpret_cast<float *>(take(w.rows_pad * 8));
+        w.row_acc = reinterpret_cast<unsigned long long *>(take(w.rows_pad * 16));
+    }
     w.total = off;
     return w;
 }
@@ -107,8 +119,25 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
         return TC_OK;
     };
 
-    TC_TRY(tc_embed_fwd(tokens, species, d->tok_table, d->species_table, w.x, w.pad, status, B, T, E,
-                        d->vocab, d->n_species, d->pad_idx, stream));
+    // Folded LayerNorms: when every layer carries the folded weights and the batch is large enough
+    // for the alternating large-tile kernels, no LayerNorm kernel runs inside the layers.
+    bool fold = bf && tc_ln_fold_supported(dt, B, T, E, F) != 0;
+    for (int l = 0; l < d->num_layers && fold; ++l) {
+        const tc_layer_weights &lw = d->layers[l];
+        fold = lw.w_qkv_ln && lw.c_qkv_ln && lw.s_qkv_ln && lw.w_fc1_ln && lw.c_fc1_ln && lw.s_fc1_ln;
+    }
+    if (fold) {
+        hipError_t e = hipMemsetAsync(w.row_acc, 0, w.rows_pad * 16, s);
+        if (e != hipSuccess) {
+            tc_set_error("tc_encoder_forward: clearing the row accumulators: %s", hipGetErrorString(e));
+            return TC_ELAUNCH;
+        }
+        TC_TRY(tc_embed_fwd_ln(tokens, species, d->tok_table, d->species_table, w.x, w.pad, status, B, T, E, d->vocab,
+                               d->n_species, d->pad_idx, w.xb, w.ln_rows, d->ln_eps, stream));
+    } else {
+        TC_TRY(tc_embed_fwd(tokens, species, d->tok_table, d->species_table, w.x, w.pad, status, B, T, E,
+                            d->vocab, d->n_species, d->pad_idx, stream));
+    }
     TC_TRY(tc_key_mask_words(w.pad, w.words, B, T, stream));
     TC_TRY(save_rep(0));
 
@@ -117,6 +146,28 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
         TC_REQUIRE(lw.ln1_g && lw.ln1_b && lw.w_qkv && lw.b_qkv && lw.w_o && lw.b_o && lw.ln2_g && lw.ln2_b &&
                        lw.w_fc1 && lw.b_fc1 && lw.w_fc2 && lw.b_fc2 && lw.rope_cos && lw.rope_sin,
                    "tc_encoder_forward: layer %d has a null weight pointer", l);
+        if (fold) {
+            // x, bf16(x) and the row statistics of bf16(x) travel together; LN1 and LN2 are applied
+            // inside the q/k/v and fc1 products (modules.py:87,100)
+            const bool last = l + 1 == d->num_layers;
+            TC_TRY(tc_gemm_ln(dt, TC_EPI_QKV_ROPE, w.xb, E, lw.w_qkv_ln, lw.c_qkv_ln, lw.s_qkv_ln, w.ln_rows, w.qkv,
+                              3 * E, M, 3 * E, E, 0.125f, lw.rope_cos, lw.rope_sin, T, 64, stream));
+            TC_TRY(tc_attn_fwd(dt, w.qkv, 3 * E, w.words, w.h, B, T, d->H, 64, stream));
+            TC_TRY(tc_gemm_residual_ln(dt, w.h, E, lw.w_o, lw.b_o, w.x, w.x, w.xb, w.row_acc, E, M, E, E, stream));
+            TC_TRY(tc_ln_rows_finalize(w.row_acc, w.ln_rows, M, E, d->ln_eps, stream));
+            TC_TRY(tc_gemm_ln(dt, TC_EPI_BIAS_GELU, w.xb, E, lw.w_fc1_ln, lw.c_fc1_ln, lw.s_fc1_ln, w.ln_rows, w.mid,
+                              w.ld_mid, M, F, E, 0.f, nullptr, nullptr, 0, 0, stream));
+            if (last) {
+                TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.x, w.x, E, M, E, F, 0.f,
+                               nullptr, nullptr, 0, 0, stream));
+            } else {
+                TC_TRY(tc_gemm_residual_ln(dt, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.x, w.x, w.xb, w.row_acc, E, M, E,
+                                           F, stream));
+                TC_TRY(tc_ln_rows_finalize(w.row_acc, w.ln_rows, M, E, d->ln_eps, stream));
+                TC_TRY(save_rep(l + 1));
+            }
+            continue;
+        }
         TC_TRY(ln(lw.ln1_g, lw.ln1_b, nullptr));
         TC_TRY(tc_gemm(dt, TC_EPI_QKV_ROPE, w.h, E, lw.w_qkv, lw.b_qkv, nullptr, w.qkv, 3 * E, M, 3 * E, E,
                        0.125f, lw.rope_cos, lw.rope_sin, T, 64, stream));

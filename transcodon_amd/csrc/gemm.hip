@@ -41,6 +41,15 @@ struct GemmParams {
     const char *aux;       // TC_EPI_DGELU: pre-activation u, element type T, leading dimension ldo
     char *out2;            // TC_EPI_BIAS_GELU_SAVE: pre-activation output, element type T
     float *colsum;         // TC_EPI_DGELU, large tiles: column sums of the result are added here (f32 [N])
+    // LayerNorm folded into the product (large alternating kernel only):
+    //   consumer (TC_EPI_QKV_ROPE / TC_EPI_BIAS_GELU): W holds gamma o W, bias holds beta W^T + b, ln_s the
+    //   row sums of the folded W, ln_rows per input row (rstd, -rstd * mean): result = rstd * acc +
+    //   (-rstd * mean) * ln_s[n] + bias[n], then the epilogue proper;
+    //   producer (TC_EPI_BIAS_RESIDUAL): out2 receives bf16(out) and row_acc += fixed-point (sum, sum of
+    //   squares) of the bf16-rounded row segment of this tile (int64, 2^-24 units, [rows, 2]).
+    const float *ln_s;
+    const float *ln_rows;
+    unsigned long long *row_acc;
     long lda_bytes, ldw_bytes;
     long slab_elems;       // split-K: f32 elements between the partial outputs of two splits
     int splits;            // split-K factor of the small-tile kernel (1 = off)
@@ -445,20 +454,39 @@ template <typename T, int EPI, int LAY = 0, int MI0 = 0, int MI1 = 8, int NI0 = 
 __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4][8], int tm, int tn, int mrow0,
                                             int ncol0, int wm, int wn, int frow, int fgrp,
                                             const char *bias_lds = nullptr, const char *rope_lds = nullptr,
-                                            const char *step_lds = nullptr) {
+                                            const char *step_lds = nullptr, const char *rows_lds = nullptr,
+                                            char *stat_lds = nullptr) {
     // LDSX: rope_lds / step_lds hold the rotary slices (q/k/v epilogue), or rope_lds the Phi table
     // (GELU epilogues)
     using namespace k256;
     constexpr bool kPreloadResidual = EPI == TC_EPI_BIAS_RESIDUAL && sizeof(T) == 2;
     const int section = EPI == TC_EPI_QKV_ROPE ? (tn * BN) / p.E : 0;
     if (bias_lds) {
-        // accumulators started at zero; the tile's 256 bias values are in this wave's LDS copy
+        // accumulators started at zero; the bias of the wave's 2 x 32 columns is in its LDS slot
+        // (column half ni >> 1, then the lane's 8 columns, then the tile of the pair)
+        if (rows_lds) {
+            // LayerNorm folded in: acc = rstd_m * acc + ((-rstd_m mean_m) * s_n + c_n)
+            int F = frow;
+            asm volatile("" : "+v"(F));            // as above: no address of this block lives through the k-loop
 #pragma unroll
-        for (int ni = NI0; ni < NI1; ++ni) {
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(
-                bias_lds + (ncol0 - tn * BN + ni_off<LAY>(ni)) * 4);
+            for (int ni = NI0; ni < NI1; ++ni) {
+                const int o = ((ni >> 1) * 32 + fgrp * 8 + (ni & 1) * 4) * 4;
+                const f32x4 c = *reinterpret_cast<const f32x4 *>(bias_lds + o);
+                const f32x4 sn = *reinterpret_cast<const f32x4 *>(bias_lds + 256 + o);
 #pragma unroll
-            for (int mi = MI0; mi < MI1; ++mi) acc[ni][mi] += b;
+                for (int mi = MI0; mi < MI1; ++mi) {
+                    const f32x2 st = *reinterpret_cast<const f32x2 *>(rows_lds + ((mi >> 2) * 64 + (mi & 3) * 16 + F) * 8);
+                    acc[ni][mi] = acc[ni][mi] * st[0] + (sn * st[1] + c);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ni = NI0; ni < NI1; ++ni) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(
+                    bias_lds + ((ni >> 1) * 32 + fgrp * 8 + (ni & 1) * 4) * 4);
+#pragma unroll
+                for (int mi = MI0; mi < MI1; ++mi) acc[ni][mi] += b;
+            }
         }
     }
     if constexpr (EPI == TC_EPI_BIAS_GELU_SAVE) {
@@ -683,6 +711,47 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
             for (int e = 0; e < 4; ++e) o[e] = (unsigned)__builtin_amdgcn_ds_bpermute(pull, (int)w[e]);
             return o;
         };
+        if constexpr (EPI == TC_EPI_BIAS_RESIDUAL && MI0 == 0 && MI1 == 8 && NI0 == 0 && NI1 == 4) {
+            if (stat_lds) {
+                // Row statistics for the LayerNorm folded into the next product: sum and sum of squares of
+                // the bf16-rounded results (the values the next product multiplies).  Per wave: its 64
+                // columns of 128 rows; the four lanes that share a row add up, lane group 0 leaves the
+                // pair as two int64 in units of 2^-24 (an exact image of the f32 partial) in the plane of
+                // this column wave; after a barrier every thread adds one (row, statistic) of the four
+                // planes to the global accumulator.  Integer adds: the result does not depend on order.
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const f32x4 v = acc[ni][mi];
+                        const uint32_t w0 = tc_pack_bf16(v[0], v[1]), w1 = tc_pack_bf16(v[2], v[3]);
+                        const float a = tc_bf16_lo(w0), b = tc_bf16_hi(w0), c = tc_bf16_lo(w1), d = tc_bf16_hi(w1);
+                        s1 += (a + b) + (c + d);
+                        s2 += (a * a + b * b) + (c * c + d * d);
+                    }
+                    s1 += __shfl_xor(s1, 16, 64);
+                    s2 += __shfl_xor(s2, 16, 64);
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (fgrp == 0) {
+                        long long q[2] = {(long long)(s1 * 16777216.f), (long long)(s2 * 16777216.f)};
+                        const int row = wm * 64 + mi_off<LAY>(mi) + frow;            // row of the tile
+                        *reinterpret_cast<u32x4 *>(stat_lds + (wn * 256 + row) * 16) = __builtin_bit_cast(u32x4, q);
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_s_barrier();
+                {
+                    const int t = threadIdx.x, row = t >> 1, which = t & 1;
+                    unsigned long long sum = 0;
+#pragma unroll
+                    for (int pl = 0; pl < 4; ++pl)
+                        sum += *reinterpret_cast<const unsigned long long *>(stat_lds + (pl * 256 + row) * 16 + which * 8);
+                    if (tm * BM + row < p.M) atomicAdd(p.row_acc + 2L * (tm * BM + row) + which, sum);
+                }
+            }
+        }
 #pragma unroll
         for (int mi = MI0; mi < MI1; ++mi) {
             const int m = mbase + mi_off<LAY>(mi) + trow;
@@ -702,9 +771,25 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
             } else {
                 static_assert(kF32Out, "bf16 results use the interleaved column order");
 #pragma unroll
-                for (int ni = NI0; ni < NI1; ++ni) {
+                for (int ni = NI0; ni < NI1; ni += (LAY == 2 ? 2 : 1)) {
                     const u32x4 w = exchange(__builtin_bit_cast(u32x4, acc[ni][mi]));
                     if (m < p.M) *reinterpret_cast<u32x4 *>(p.out + (orow + ni_off<LAY>(ni)) * 4) = w;
+                    if constexpr (LAY == 2) {
+                        // interleaved column order: the pair's second tile is the lane's next 4 columns
+                        const u32x4 w2 = exchange(__builtin_bit_cast(u32x4, acc[ni + 1][mi]));
+                        if (m < p.M) *reinterpret_cast<u32x4 *>(p.out + (orow + ni_off<LAY>(ni + 1)) * 4) = w2;
+                        if constexpr (EPI == TC_EPI_BIAS_RESIDUAL) {
+                            if (p.out2 && m < p.M) {              // bf16 copy for the folded LayerNorm's product
+                                const f32x4 f = __builtin_bit_cast(f32x4, w), f2 = __builtin_bit_cast(f32x4, w2);
+                                u32x4 h;
+                                h[0] = tc_pack_bf16(f[0], f[1]);
+                                h[1] = tc_pack_bf16(f[2], f[3]);
+                                h[2] = tc_pack_bf16(f2[0], f2[1]);
+                                h[3] = tc_pack_bf16(f2[2], f2[3]);
+                                *reinterpret_cast<u32x4 *>(p.out2 + (orow + ni_off<LAY>(ni)) * 2) = h;
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -938,10 +1023,15 @@ constexpr int BM = 256, BN = 256;
 constexpr int HALF_BYTES = 128 * 128;           // one half-tile (16 KiB)
 constexpr int DBUF_BYTES = 4 * HALF_BYTES;      // A0 A1 B0 B1
 constexpr int SLOT_A0 = 0, SLOT_A1 = HALF_BYTES, SLOT_B0 = 2 * HALF_BYTES, SLOT_B1 = 3 * HALF_BYTES;
-// per wave, after the operand buffers: the tile's 256 bias values (1 KiB), the rotary cos and sin
-// of the wave's first 16 rows x the lane's 4 pairs (2 KiB), rows 16 and 80 of both tables (512 B)
+// per wave, after the operand buffers: a 1 KiB slot with the bias of the wave's 2 x 32 columns (256 B)
+// and, with a folded LayerNorm, the folded weight's row sums for the same columns (next 256 B); the
+// rotary cos and sin of the wave's first 16 rows x the lane's 4 pairs (2 KiB); rows 16 and 80 of both
+// tables (512 B)
 constexpr int BIAS_OFF = 2 * DBUF_BYTES, ROPE_OFF = BIAS_OFF + 8 * 1024, STEP_OFF = ROPE_OFF + 8 * 2048;
-constexpr int LDS_BYTES = STEP_OFF + 8 * 512;   // 156 KiB
+// after those: (rstd, -rstd * mean) of the tile's 256 rows when a LayerNorm is folded in (one copy
+// per row group of 128 rows; staged by column wave 0 of the group, published by the phase barriers)
+constexpr int ROWS_OFF = STEP_OFF + 8 * 512;
+constexpr int LDS_BYTES = ROWS_OFF + 2 * 1024;  // 158 KiB
 }  // namespace k256x
 
 constexpr bool piecewise_epilogue(int epi) {
@@ -960,7 +1050,7 @@ constexpr bool piecewise_epilogue(int epi) {
     } while (0)
 #endif
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool FOLD = false>
 __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     using namespace k256x;
     static_assert(sizeof(T) == 2, "bf16 only");
@@ -968,9 +1058,10 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     // of the next tile's first k-tile, after that phase's LDS-DMA issue and before its LDS reads:
     // nothing then waits for their stores.  The others run as one block between two tiles.
     constexpr bool kPiece = piecewise_epilogue(EPI);
-    // bf16 results use the interleaved column order (16-byte stores); f32 results are 16 bytes
-    // per lane and accumulator tile already
-    constexpr int kLay = (EPI == TC_EPI_BIAS_RESIDUAL || EPI == TC_EPI_PLAIN_F32) ? 1 : 2;
+    // bf16 results use the interleaved column order (16-byte stores); so does the f32 residual result
+    // (two 16-byte stores side by side: 128 contiguous bytes per row, and its optional bf16 copy is one
+    // 16-byte store); the plain f32 result keeps the plain order
+    constexpr int kLay = EPI == TC_EPI_PLAIN_F32 ? 1 : 2;
     constexpr int kTileStores = EPI == TC_EPI_BIAS_GELU_SAVE ? 32 : (kLay == 2 ? 16 : 32);   // store instructions per wave
     constexpr bool kGeluTable = EPI == TC_EPI_BIAS_GELU || EPI == TC_EPI_BIAS_GELU_SAVE;
     static_assert(kPhiEntries * 4 <= STEP_OFF - ROPE_OFF, "the Phi table takes the place of the rotary slices");
@@ -1052,8 +1143,23 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     char *const bias_slot = smem + BIAS_OFF + wid * 1024;
     char *const rope_slot = smem + ROPE_OFF + wid * 2048;
     char *const step_slot = smem + STEP_OFF + wid * 512;
+    constexpr bool ln_fold = FOLD;                 // a LayerNorm folded into this product (p.ln_rows, p.ln_s)
+    static_assert(!FOLD || EPI == TC_EPI_QKV_ROPE || EPI == TC_EPI_BIAS_GELU, "no folded form of this epilogue");
+    char *const rows_slot = smem + ROWS_OFF + wr * 1024;
     auto stage_epilogue_inputs = [&](int tm, int tn) {
-        if (lds_bias) glds16(reinterpret_cast<const char *>(p.bias + tn * BN + lane * 4), bias_slot);
+        int L = lane;
+        asm volatile("" : "+v"(L));                // the address arithmetic below stays here, out of the k-loop's live set
+        // lanes 0..7: the wave's 32 columns of the tile's first column half, 8..15: of the second;
+        // lanes 16..31 the same columns of the folded weight's row sums
+        if (lds_bias && L < (ln_fold ? 32 : 16)) {
+            const float *vec = L < 16 ? p.bias : p.ln_s;
+            glds16(reinterpret_cast<const char *>(vec + tn * BN + ((L >> 3) & 1) * 128 + wc * 32 + (L & 7) * 4), bias_slot);
+        }
+        if (ln_fold && wc == 0) {
+            // rows wr*64 .. +63 (lanes 0..31, two rows each) and 128 + wr*64 .. (lanes 32..63)
+            const int r0 = tm * BM + (L >> 5) * 128 + wr * 64 + (L & 31) * 2;
+            glds16(reinterpret_cast<const char *>(p.ln_rows + 2L * r0), rows_slot);
+        }
         if constexpr (EPI == TC_EPI_QKV_ROPE) {
             if ((tn * BN) / p.E < 2) {
                 // lane (fgrp, frow): row tile_pos0 + wr*64 + frow, pairs ((wc*32 + fgrp*8) % 64) / 2 .. + 3
@@ -1151,7 +1257,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         const int mrow0 = tm * BM + wr * 64 + frow, ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);
         epilogue256<T, EPI, kLay, 0, 8, 0, 4, EPI == TC_EPI_QKV_ROPE || kGeluTable>(
             p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, lds_bias ? bias_slot : nullptr,
-            kGeluTable ? smem + ROPE_OFF : rope_slot, step_slot);
+            kGeluTable ? smem + ROPE_OFF : rope_slot, step_slot, ln_fold ? rows_slot : nullptr);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -1339,7 +1445,8 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             if (wr == 0) TC_XBAR();               // row group 1's last phase
             TC_STAMP(e0);
             epilogue256<T, EPI, kLay, 0, 8, 0, 4, kGeluTable>(p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, nullptr,
-                                                              smem + ROPE_OFF);
+                                                              smem + ROPE_OFF, nullptr, nullptr,
+                                                              p.row_acc ? smem + BIAS_OFF : nullptr);
 #ifdef TC_GEMM_STAMPS
             TC_STAMP(e1);
             c_epi += e1 - e0;
@@ -1378,6 +1485,13 @@ int g_num_cus = 0;
 #ifdef TC_GEMM_STAMPS
 unsigned long long *g_stamps = nullptr;
 #endif
+
+// TC_GEMM_ALT=0 selects the single-group schedule of the large tile
+int alt_schedule_enabled() {
+    static int alt = -1;
+    if (alt < 0) { const char *e = getenv("TC_GEMM_ALT"); alt = e ? atoi(e) != 0 : 1; }
+    return alt;
+}
 
 template <typename T, int EPI>
 int launch(const GemmParams &p0, bool big, hipStream_t stream) {
@@ -1422,13 +1536,27 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
         p.stamps = g_stamps;
         { const char *e = getenv("TC_GEMM_NOSTORE"); p.nostore = e ? atoi(e) : 0; }
 #endif
-        static int alt = -1;            // TC_GEMM_ALT=0 selects the single-group schedule
-        if (alt < 0) { const char *e = getenv("TC_GEMM_ALT"); alt = e ? atoi(e) != 0 : 1; }
+        const int alt = alt_schedule_enabled();
         // the alternating kernel's rotary epilogue steps through a tile by angle addition: no
         // sequence boundary inside a 256-row tile, head dimension 64
         bool use_alt = alt != 0;
         if (EPI == TC_EPI_QKV_ROPE && (p.T % 256 != 0 || p.head_dim != 64 || p.pos)) use_alt = false;
-        if (use_alt) {
+        constexpr bool kHasFold = EPI == TC_EPI_QKV_ROPE || EPI == TC_EPI_BIAS_GELU;
+        if (use_alt && kHasFold && p.ln_rows) {
+            if constexpr (kHasFold) {
+                static bool attr_set_f = false;
+                if (!attr_set_f) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256x_kernel<T, EPI, true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, k256x::LDS_BYTES);
+                    if (e != hipSuccess) {
+                        tc_set_error("tc_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                        return TC_ELAUNCH;
+                    }
+                    attr_set_f = true;
+                }
+                TC_LAUNCH((gemm256x_kernel<T, EPI, true>), dim3(grid), dim3(512), k256x::LDS_BYTES, stream, p);
+            }
+        } else if (use_alt) {
             static bool attr_set_x = false;
             if (!attr_set_x) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256x_kernel<T, EPI>),
@@ -1489,7 +1617,8 @@ extern "C" void tc_debug_set_stamp_buffer(void *p) { g_stamps = static_cast<unsi
 static int gemm_impl(int dtype, int epilogue, const void *A, int lda, const void *W, const float *bias,
                      const float *residual, const void *aux, void *out, void *out2, int ldo, int M, int N,
                      int K, int splits, float q_scale, const float *rope_cos, const float *rope_sin, int T,
-                     int head_dim, void *stream, const int32_t *pos = nullptr) {
+                     int head_dim, void *stream, const int32_t *pos = nullptr, const float *ln_s = nullptr,
+                     const float *ln_rows = nullptr, unsigned long long *row_acc = nullptr) {
     TC_REQUIRE(dtype == TC_BF16 || dtype == TC_F32, "tc_gemm: bad dtype %d", dtype);
     const int esz = dtype == TC_BF16 ? 2 : 4;
     const int kt = 128 / esz;
@@ -1559,6 +1688,15 @@ static int gemm_impl(int dtype, int epilogue, const void *A, int lda, const void
         if (force == -2) { const char *e = getenv("TC_GEMM_TILE"); force = e ? atoi(e) : -1; }
         if (force == 128) big = false;
     }
+    if (ln_s || ln_rows || row_acc) {
+        // the folded LayerNorm lives in the alternating large-tile kernel's epilogues only
+        bool ok = big && alt_schedule_enabled();
+        if (epilogue == TC_EPI_QKV_ROPE && (T % 256 != 0 || head_dim != 64 || pos)) ok = false;
+        TC_REQUIRE(ok, "tc_gemm: the folded LayerNorm needs the large alternating kernel (M=%d N=%d K=%d T=%d)", M, N, K, T);
+        p.ln_s = ln_s;
+        p.ln_rows = ln_rows;
+        p.row_acc = row_acc;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     // DGELU: out2 (optional, f32 [N]) receives += column sums of the result.  The large tile adds
     // them in its epilogue; the other kernels are followed by a pass over the result.
@@ -1591,6 +1729,45 @@ extern "C" int tc_gemm_qkv_packed(int dtype, const void *A, int lda, const void 
     TC_REQUIRE(pos != nullptr && table_rows > 0, "tc_gemm_qkv_packed: needs the row positions and the table length");
     return gemm_impl(dtype, TC_EPI_QKV_ROPE, A, lda, W, bias, nullptr, nullptr, out, nullptr, ldo, M, N, K, 1, q_scale,
                      rope_cos, rope_sin, table_rows, head_dim, stream, pos);
+}
+
+// LayerNorm folded into the products on either side of it (see the header).
+extern "C" int tc_gemm_ln(int dtype, int epilogue, const void *A, int lda, const void *Wf, const float *c,
+                          const float *s, const float *rows, void *out, int ldo, int M, int N, int K, float q_scale,
+                          const float *rope_cos, const float *rope_sin, int T, int head_dim, void *stream) {
+    TC_REQUIRE(epilogue == TC_EPI_QKV_ROPE || epilogue == TC_EPI_BIAS_GELU, "tc_gemm_ln: epilogue %d has no folded form", epilogue);
+    TC_REQUIRE(c && s && rows && tc_aligned16(s) && tc_aligned16(rows), "tc_gemm_ln: needs aligned c, s and row statistics");
+    return gemm_impl(dtype, epilogue, A, lda, Wf, c, nullptr, nullptr, out, nullptr, ldo, M, N, K, 1, q_scale, rope_cos,
+                     rope_sin, T, head_dim, stream, nullptr, s, rows, nullptr);
+}
+
+extern "C" int tc_gemm_residual_ln(int dtype, const void *A, int lda, const void *W, const float *bias,
+                                   const float *residual, void *out, void *out_bf16, unsigned long long *row_acc,
+                                   int ldo, int M, int N, int K, void *stream) {
+    TC_REQUIRE(out_bf16 && row_acc && tc_aligned16(out_bf16) && tc_aligned16(row_acc),
+               "tc_gemm_residual_ln: needs the bf16 copy and the row accumulators");
+    return gemm_impl(dtype, TC_EPI_BIAS_RESIDUAL, A, lda, W, bias, residual, nullptr, out, out_bf16, ldo, M, N, K, 1, 0.f,
+                     nullptr, nullptr, 0, 0, stream, nullptr, nullptr, nullptr, row_acc);
+}
+
+// 1 when a forward of M = B*T rows can run with its LayerNorms folded into the products: every
+// product of a layer (N = 3E, E, F) takes the alternating large-tile kernel and the rotary epilogue
+// its table-slice form.
+extern "C" int tc_ln_fold_supported(int dtype, int B, int T, int E, int F) {
+    if (dtype != TC_BF16 || B <= 0 || T <= 0 || !alt_schedule_enabled()) return 0;
+    if (g_num_cus == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return 0;
+        g_num_cus = cus;
+    }
+    { const char *e = getenv("TC_GEMM_TILE"); if (e && atoi(e) == 128) return 0; }
+    const long M = (long)B * T;
+    if (E % 256 != 0 || F % 256 != 0 || T % 256 != 0) return 0;
+    if (((M + 255) / 256) * (E / 256) < g_num_cus) return 0;
+    if (M * (F + 64) * 2 >= (1L << 32)) return 0;
+    return 1;
 }
 
 extern "C" int tc_gemm_train(int dtype, int epilogue, const void *A, int lda, const void *W, const float *bias,

@@ -13,7 +13,11 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t *__restrict__ 
                                                     const float *__restrict__ sp_table,
                                                     float *__restrict__ x, uint8_t *pad_flags,
                                                     int32_t *bad_index, int M, int T, int E,
-                                                    int vocab, int n_species, int pad_idx) {
+                                                    int vocab, int n_species, int pad_idx,
+                                                    uint16_t *__restrict__ xb, float *__restrict__ ln_rows,
+                                                    float eps) {
+    // xb / ln_rows (optional, together): bf16 copy of the row and (rstd, -rstd * mean) of that copy,
+    // for a first LayerNorm folded into the product that follows
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -27,15 +31,90 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t *__restrict__ 
     }
     float *dst = x + (long)row * E;
     if (pad || bad) {
-        for (int c = lane * 4; c < E; c += 256) *reinterpret_cast<f32x4 *>(dst + c) = f32x4{0, 0, 0, 0};
+        for (int c = lane * 4; c < E; c += 256) {
+            *reinterpret_cast<f32x4 *>(dst + c) = f32x4{0, 0, 0, 0};
+            if (xb) *reinterpret_cast<u32x2 *>(xb + (long)row * E + c) = u32x2{0, 0};
+        }
+        if (ln_rows && lane == 0) *reinterpret_cast<f32x2 *>(ln_rows + 2L * row) = f32x2{rsqrtf(eps), 0.f};
         return;
     }
     const float *a = tok_table + (long)tok * E;
     const float *b = sp_table + (long)sp * E;
+    float s1 = 0.f, s2 = 0.f;
     for (int c = lane * 4; c < E; c += 256) {
         const f32x4 va = *reinterpret_cast<const f32x4 *>(a + c);
         const f32x4 vb = *reinterpret_cast<const f32x4 *>(b + c);
-        *reinterpret_cast<f32x4 *>(dst + c) = va + vb;
+        const f32x4 v = va + vb;
+        *reinterpret_cast<f32x4 *>(dst + c) = v;
+        if (xb) {
+            u32x2 w;
+            w[0] = tc_pack_bf16(v[0], v[1]);
+            w[1] = tc_pack_bf16(v[2], v[3]);
+            *reinterpret_cast<u32x2 *>(xb + (long)row * E + c) = w;
+            const float p = tc_bf16_lo(w[0]), q = tc_bf16_hi(w[0]), r = tc_bf16_lo(w[1]), t = tc_bf16_hi(w[1]);
+            s1 += (p + q) + (r + t);
+            s2 += (p * p + q * q) + (r * r + t * t);
+        }
+    }
+    if (ln_rows) {
+        s1 = tc_wave_sum(s1);
+        s2 = tc_wave_sum(s2);
+        if (lane == 0) {
+            const double mean = (double)s1 / E;
+            double var = (double)s2 / E - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            *reinterpret_cast<f32x2 *>(ln_rows + 2L * row) = f32x2{rstd, (float)(-(double)rstd * mean)};
+        }
+    }
+}
+
+// ---- LayerNorm folded into the neighbouring products: row statistics and weight preparation ------
+// The residual product leaves, per row, the exact integer sums (units of 2^-24) of its bf16-rounded
+// results and of their squares; this turns them into (rstd, -rstd * mean) and clears the
+// accumulators for the next product.
+__global__ __launch_bounds__(256) void ln_rows_finalize_kernel(unsigned long long *__restrict__ row_acc,
+                                                               float *__restrict__ ln_rows, int M, int E, float eps) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    const double scale = 1.0 / 16777216.0;
+    const double s1 = (double)(long long)row_acc[2L * row] * scale, s2 = (double)(long long)row_acc[2L * row + 1] * scale;
+    row_acc[2L * row] = 0;
+    row_acc[2L * row + 1] = 0;
+    const double mean = s1 / E;
+    double var = s2 / E - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    *reinterpret_cast<f32x2 *>(ln_rows + 2L * row) = f32x2{rstd, (float)(-(double)rstd * mean)};
+}
+
+// One wave per output feature n: Wf[n,:] = bf16(gamma o W[n,:]), s[n] = sum_k Wf[n,k] (of the rounded
+// values: it must cancel what the product accumulates), c[n] = sum_k beta[k] W[n,k] + bias[n].
+__global__ __launch_bounds__(256) void ln_fold_kernel(const float *__restrict__ W, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, const float *__restrict__ bias,
+                                                      uint16_t *__restrict__ Wf, float *__restrict__ s_out,
+                                                      float *__restrict__ c_out, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float s = 0.f, c = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(W + (long)n * K + k);
+        const f32x4 g = *reinterpret_cast<const f32x4 *>(gamma + k);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(beta + k);
+        const f32x4 f = w * g;
+        u32x2 o;
+        o[0] = tc_pack_bf16(f[0], f[1]);
+        o[1] = tc_pack_bf16(f[2], f[3]);
+        *reinterpret_cast<u32x2 *>(Wf + (long)n * K + k) = o;
+        s += (tc_bf16_lo(o[0]) + tc_bf16_hi(o[0])) + (tc_bf16_lo(o[1]) + tc_bf16_hi(o[1]));
+        c += (w[0] * b[0] + w[1] * b[1]) + (w[2] * b[2] + w[3] * b[3]);
+    }
+    s = tc_wave_sum(s);
+    c = tc_wave_sum(c);
+    if (lane == 0) {
+        s_out[n] = s;
+        c_out[n] = c + (bias ? bias[n] : 0.f);
     }
 }
 
@@ -515,22 +594,63 @@ extern "C" int tc_mean_pool_packed(const float *rep, const int32_t *row_start, c
     return TC_OK;
 }
 
-extern "C" int tc_embed_fwd(const int32_t *tokens, const int32_t *species, const float *tok_table,
-                            const float *species_table, float *x, uint8_t *pad_flags,
-                            int32_t *bad_index, int B, int T, int E, int vocab, int n_species,
-                            int pad_idx, void *stream) {
+static int embed_impl(const int32_t *tokens, const int32_t *species, const float *tok_table,
+                      const float *species_table, float *x, uint8_t *pad_flags, int32_t *bad_index, int B, int T,
+                      int E, int vocab, int n_species, int pad_idx, void *xb, float *ln_rows, float eps,
+                      void *stream) {
     TC_REQUIRE(tokens && species && tok_table && species_table && x, "tc_embed_fwd: null operand");
     TC_REQUIRE(B > 0 && T > 0 && E > 0 && E % 4 == 0, "tc_embed_fwd: bad shape B=%d T=%d E=%d", B, T, E);
     TC_REQUIRE(tc_aligned16(tok_table) && tc_aligned16(species_table) && tc_aligned16(x),
                "tc_embed_fwd: tables and output must be 16-byte aligned");
+    TC_REQUIRE((xb == nullptr) == (ln_rows == nullptr) && tc_aligned16(xb) && tc_aligned16(ln_rows),
+               "tc_embed_fwd_ln: the bf16 copy and the row statistics come together, 16-byte aligned");
     const long M = (long)B * T;
     TC_REQUIRE(M < (1L << 31), "tc_embed_fwd: too many rows");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    TcProfScope prof(TC_PROF_EMBED, s, (double)M * (4.0 + 4.0 * E));
+    TcProfScope prof(TC_PROF_EMBED, s, (double)M * (4.0 + (xb ? 6.0 : 4.0) * E));
     TC_LAUNCH(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, tokens, species,
                        tok_table, species_table, x, pad_flags, bad_index, (int)M, T, E, vocab,
-                       n_species, pad_idx);
+                       n_species, pad_idx, static_cast<uint16_t *>(xb), ln_rows, eps);
     TC_CHECK_LAUNCH("tc_embed_fwd");
+    return TC_OK;
+}
+
+extern "C" int tc_embed_fwd(const int32_t *tokens, const int32_t *species, const float *tok_table,
+                            const float *species_table, float *x, uint8_t *pad_flags,
+                            int32_t *bad_index, int B, int T, int E, int vocab, int n_species,
+                            int pad_idx, void *stream) {
+    return embed_impl(tokens, species, tok_table, species_table, x, pad_flags, bad_index, B, T, E, vocab, n_species,
+                      pad_idx, nullptr, nullptr, 0.f, stream);
+}
+
+extern "C" int tc_embed_fwd_ln(const int32_t *tokens, const int32_t *species, const float *tok_table,
+                               const float *species_table, float *x, uint8_t *pad_flags, int32_t *bad_index, int B,
+                               int T, int E, int vocab, int n_species, int pad_idx, void *xb, float *ln_rows,
+                               float eps, void *stream) {
+    TC_REQUIRE(xb && ln_rows, "tc_embed_fwd_ln: null operand");
+    return embed_impl(tokens, species, tok_table, species_table, x, pad_flags, bad_index, B, T, E, vocab, n_species,
+                      pad_idx, xb, ln_rows, eps, stream);
+}
+
+extern "C" int tc_ln_rows_finalize(unsigned long long *row_acc, float *ln_rows, int M, int E, float eps, void *stream) {
+    TC_REQUIRE(row_acc && ln_rows && M > 0 && E > 0, "tc_ln_rows_finalize: bad operand");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TcProfScope prof(TC_PROF_LAYERNORM, s, (double)M * 40.0);      // 16 B read, 16 B cleared, 8 B written per row
+    TC_LAUNCH(ln_rows_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, row_acc, ln_rows, M, E, eps);
+    TC_CHECK_LAUNCH("tc_ln_rows_finalize");
+    return TC_OK;
+}
+
+extern "C" int tc_ln_fold_weights(const float *W, const float *gamma, const float *beta, const float *bias, void *Wf,
+                                  float *s_out, float *c_out, int N, int K, void *stream) {
+    TC_REQUIRE(W && gamma && beta && Wf && s_out && c_out, "tc_ln_fold_weights: null operand");
+    TC_REQUIRE(N > 0 && K > 0 && K % 4 == 0, "tc_ln_fold_weights: bad shape N=%d K=%d", N, K);
+    TC_REQUIRE(tc_aligned16(W) && tc_aligned16(gamma) && tc_aligned16(beta) && tc_aligned16(Wf),
+               "tc_ln_fold_weights: operands must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TC_LAUNCH(ln_fold_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, W, gamma, beta, bias,
+              static_cast<uint16_t *>(Wf), s_out, c_out, N, K);
+    TC_CHECK_LAUNCH("tc_ln_fold_weights");
     return TC_OK;
 }
 

@@ -74,6 +74,7 @@ class ProteinBertModel(nn.Module):
         self.structure_linear = RNA_2D_RobertaLMHead(embed_dim=E, output_dim=3)
         self.compute_dtype = None       # None: follow the parameter dtype (f32 unless .bfloat16())
         self.check_indices = True       # raise IndexError on out-of-range token / species ids
+        self.fold_layernorm = True      # bf16 inference: LayerNorms of the layers folded into the products
         self._pack = {}
         self._workspace = None
         self._train_workspace = None
@@ -154,7 +155,7 @@ class ProteinBertModel(nn.Module):
                self.structure_linear.bias]
         layer_params = [p for l in self.layers for p in l.parameters()]
         rope_len = max(512, 1 << (T - 1).bit_length())
-        key = (dtype, str(device), rope_len, _param_key(own + layer_params))
+        key = (dtype, str(device), rope_len, bool(self.fold_layernorm), _param_key(own + layer_params))
         if self._pack.get("key") == key:
             return self._pack
         with torch.no_grad():
@@ -177,6 +178,11 @@ class ProteinBertModel(nn.Module):
                              "w_fc1", "b_fc1", "w_fc2", "b_fc2"):
                     setattr(layers[i], name, pk[name].data_ptr())
                 layers[i].rope_cos, layers[i].rope_sin = cos.data_ptr(), sin.data_ptr()
+                if dtype == torch.bfloat16 and self.fold_layernorm:
+                    folded = self._fold_layer(l, pk, device)
+                    per_layer.append(folded)
+                    for name, t in folded.items():
+                        setattr(layers[i], name, t.data_ptr())
             d = EncoderDesc()
             d.dtype = _lib.TC_BF16 if dtype == torch.bfloat16 else _lib.TC_F32
             d.num_layers, d.E, d.F = len(self.layers), self.args.embed_dim, self.args.ffn_embed_dim
@@ -190,6 +196,30 @@ class ProteinBertModel(nn.Module):
                 setattr(d, name, keep[name].data_ptr())
         self._pack = {"key": key, "desc": d, "layers": layers, "keep": keep, "per_layer": per_layer}
         return self._pack
+
+    @staticmethod
+    def _fold_layer(l, pk, device):
+        """The layer's two LayerNorms folded into the q/k/v and fc1 weights (tc_ln_fold_weights):
+        bf16(gamma o W), its row sums, and beta W^T + b.  With these in the descriptor and a batch
+        large enough for the large-tile kernels, the bf16 forward runs no LayerNorm kernel inside the
+        layers (modules.py:87,100 become part of the products on either side)."""
+        lib = _lib.load()
+        a = l.self_attn
+        wq = torch.cat([a.q_proj.weight.detach(), a.k_proj.weight.detach(), a.v_proj.weight.detach()]).float().contiguous()
+        w1 = l.fc1.weight.detach().float().contiguous()
+        out = {}
+        stream = torch.cuda.current_stream(device).cuda_stream
+        for tag, W, g, b, bias in (("qkv", wq, pk["ln1_g"], pk["ln1_b"], pk["b_qkv"]),
+                                   ("fc1", w1, pk["ln2_g"], pk["ln2_b"], pk["b_fc1"])):
+            N, K = W.shape
+            wf = torch.empty(N, K, dtype=torch.bfloat16, device=device)
+            s = torch.empty(N, dtype=torch.float32, device=device)
+            c = torch.empty(N, dtype=torch.float32, device=device)
+            check(lib.tc_ln_fold_weights(W.data_ptr(), g.data_ptr(), b.data_ptr(), bias.data_ptr(), wf.data_ptr(),
+                                         s.data_ptr(), c.data_ptr(), N, K, stream), "tc_ln_fold_weights")
+            out[f"w_{tag}_ln"], out[f"s_{tag}_ln"], out[f"c_{tag}_ln"] = wf, s, c
+        torch.cuda.current_stream(device).synchronize()      # W and the temporaries may be freed after this
+        return out
 
     def _get_workspace(self, nbytes, device, train=False):
         attr = "_train_workspace" if train else "_workspace"
