@@ -428,6 +428,8 @@ def main():
                     help="train = --config 4 (kept for older command lines)")
     ap.add_argument("--train-batch", type=int, default=64)
     ap.add_argument("--train-seq-len", type=int, default=1024)
+    ap.add_argument("--no-fold", action="store_true",
+                    help="inference configs: run the LayerNorms of the layers as separate kernels")
     ap.add_argument("--struct-labels", action="store_true",
                     help="config 4 with structure labels on half of the positions (the 0.4-weighted second loss term)")
     ap.add_argument("--n-seqs", type=int, default=None,
@@ -480,6 +482,7 @@ def main():
     sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.to(dev).eval().set_compute_dtype(torch.bfloat16)
     model.check_indices = False          # inputs are generated in range; avoids a host sync per step
+    model.fold_layernorm = not args.no_fold
 
     if args.config == 2:
         B, T, n_micro = B_PER_GPU, SEQ_LEN, 1
@@ -555,7 +558,9 @@ def main():
     lib.tc_prof_enable(0)
     prof = {name: _lib.prof_collect(kind) for name, kind in
             (("gemm", _lib.PROF_GEMM), ("attn", _lib.PROF_ATTN), ("layernorm", _lib.PROF_LAYERNORM),
-             ("embed", _lib.PROF_EMBED), ("head", _lib.PROF_HEAD), ("decode", _lib.PROF_DECODE))}
+             ("embed", _lib.PROF_EMBED), ("head", _lib.PROF_HEAD), ("decode", _lib.PROF_DECODE),
+             ("ln_rows", _lib.PROF_LN_ROWS))}
+    folded = bool(model.fold_layernorm) and lib.tc_ln_fold_supported(_lib.TC_BF16, B, T, 768, 3072) != 0
 
     # sanity: the decoded bases of the last micro-batch translate back to its proteins
     flat = bytes(bases.cpu().numpy()).decode("ascii")
@@ -575,13 +580,16 @@ def main():
         M, E, F = B * T, 768, 3072
         per_layer = (M * E * 2 + 3 * E * E * 2 + M * 3 * E * 2) + (M * E * 2 + E * E * 2 + 2 * M * E * 4) + \
                     (M * E * 2 + F * E * 2 + M * F * 2) + (M * F * 2 + E * F * 2 + 2 * M * E * 4)
-        gemm_bytes = (12 * per_layer + M * E * 2 + 2 * E * E * 2 + M * 2 * E * 2) * args.steps * n_micro
+        # folded LayerNorms: 23 of the 24 residual products also write the bf16 copy of their result
+        extra = 23 * M * E * 2 if folded else 0
+        gemm_bytes = (12 * per_layer + extra + M * E * 2 + 2 * E * E * 2 + M * 2 * E * 2) * args.steps * n_micro
         by_kernel = {}
         for name, bound, unit, scale, peak in (("attn", "mfma", "TFLOP/s", 1e12, PEAK_BF16_TFLOPS),
                                                ("layernorm", "hbm", "GB/s", 1e9, PEAK_HBM_GBS),
                                                ("embed", "hbm", "GB/s", 1e9, PEAK_HBM_GBS),
                                                ("head", "hbm", "GB/s", 1e9, PEAK_HBM_GBS),
-                                               ("decode", "hbm", "GB/s", 1e9, PEAK_HBM_GBS)):
+                                               ("decode", "hbm", "GB/s", 1e9, PEAK_HBM_GBS),
+                                               ("ln_rows", "hbm", "GB/s", 1e9, PEAK_HBM_GBS)):
             cnt, kms, work = prof[name]
             if kms > 0:
                 ach = work / (kms * 1e-3) / scale
@@ -604,6 +612,8 @@ def main():
                        "codons_per_s": round(tokens_total / elapsed / 3, 1),
                        "weights": "random init N(0,0.02), 89.8M params", "parallelism": f"batch-sharded x{world}",
                        "rccl_ranks": rccl_ranks, "backend": args.backend if world > 1 else None,
+                       "layernorm": ("24 of 25 folded into the q/k/v, out-proj, fc1 and fc2 products" if folded
+                                     else "separate kernels"),
                        "with_host_io_tokens_per_s": round(tokens_total / elapsed_io, 1),
                        "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3)},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel<bf16, EPI> (all GEMM launches of the step)",

@@ -474,7 +474,8 @@ int tc_encoder_forward_packed(const tc_encoder_desc *desc, const int32_t *tokens
 #define TC_PROF_EMBED 3
 #define TC_PROF_HEAD 4
 #define TC_PROF_DECODE 5
-#define TC_PROF_NKINDS 6
+#define TC_PROF_LN_ROWS 6      /* tc_ln_rows_finalize */
+#define TC_PROF_NKINDS 7
 /*
  * When enabled, every launch of the selected kernel families carries a start and a stop HIP
  * event on its own dispatch (hipExtLaunchKernelGGL: the kernel's own timestamps, no marker

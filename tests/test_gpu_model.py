@@ -258,6 +258,49 @@ def test_headline_kernel_mix_bf16_against_oracle(full_sd, full_bf16):
     assert float(d.max()) < 0.15
 
 
+def test_folded_layernorm_forward_against_separate_kernels_and_oracle(full_sd, full_bf16):
+    """The same 64 x 512 bf16 batch with the layers' LayerNorms folded into the products (default for
+    batches this large) and as separate kernels: both within the bf16 tolerance of the oracle, the folded
+    run no further from it than the separate one by more than a quarter, 23 row-statistics launches
+    where 24 LayerNorm launches were, and padded rows handled (one sequence is half padding)."""
+    from transcodon_amd import _lib
+    rng = np.random.default_rng(99)
+    B, T = 64, 512
+    tok = rng.integers(5, 10, (B, T))
+    tok[:, 0] = O.CLS
+    tok[:, -1] = O.EOS
+    tok[3, 256:] = 1                                   # padding tail
+    tok[3, 255] = O.EOS
+    sp = rng.integers(0, 1438, B)
+    t_d, s_d = torch.from_numpy(tok).to(DEV), torch.from_numpy(sp).to(DEV)
+    lib = _lib.load()
+    assert lib.tc_ln_fold_supported(_lib.TC_BF16, B, T, 768, 3072) == 1
+    runs = {}
+    for fold in (True, False):
+        full_bf16.fold_layernorm = fold
+        lib.tc_prof_reset()
+        lib.tc_prof_enable(1)
+        with torch.no_grad():
+            out = full_bf16(t_d, s_d)
+        torch.cuda.synchronize()
+        lib.tc_prof_enable(0)
+        runs[fold] = (out["logits"].float().cpu().numpy(), _lib.prof_collect(_lib.PROF_LN_ROWS)[0],
+                      _lib.prof_collect(_lib.PROF_LAYERNORM)[0])
+    full_bf16.fold_layernorm = True
+    assert runs[True][1] == 23 and runs[True][2] == 1
+    assert runs[False][1] == 0 and runs[False][2] == 25
+    rows = [0, 3, 41]
+    ref = O.forward(full_sd, O.FULL, torch.from_numpy(tok[rows]), torch.from_numpy(sp[rows]))["logits"].numpy()
+    keep = tok[rows] != 1
+    err = {}
+    for fold in (True, False):
+        got = runs[fold][0][rows]
+        _check(got, ref, keep, torch.bfloat16)
+        err[fold] = float(np.sqrt(np.mean((got - ref)[keep] ** 2)))
+    print(f"\nrms logit error against the oracle: folded {err[True]:.4e}, separate kernels {err[False]:.4e}")
+    assert err[True] <= 1.25 * err[False] + 1e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_multihead_attention_module_against_oracle(dtype):
     """MultiheadAttention.forward on its own (the sub-module API of multihead_attention.py:162-408):

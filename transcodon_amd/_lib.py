@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(_HERE, "csrc", "libtran
 TC_F32, TC_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_QKV_ROPE = 0, 1, 2, 3
 EPI_PLAIN_F32, EPI_BIAS_GELU_SAVE, EPI_DGELU = 4, 5, 6
-PROF_GEMM, PROF_ATTN, PROF_LAYERNORM, PROF_EMBED, PROF_HEAD, PROF_DECODE = range(6)
+PROF_GEMM, PROF_ATTN, PROF_LAYERNORM, PROF_EMBED, PROF_HEAD, PROF_DECODE, PROF_LN_ROWS = range(7)
 
 vp = C.c_void_p
 

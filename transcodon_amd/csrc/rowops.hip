@@ -635,7 +635,7 @@ extern "C" int tc_embed_fwd_ln(const int32_t *tokens, const int32_t *species, co
 extern "C" int tc_ln_rows_finalize(unsigned long long *row_acc, float *ln_rows, int M, int E, float eps, void *stream) {
     TC_REQUIRE(row_acc && ln_rows && M > 0 && E > 0, "tc_ln_rows_finalize: bad operand");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    TcProfScope prof(TC_PROF_LAYERNORM, s, (double)M * 40.0);      // 16 B read, 16 B cleared, 8 B written per row
+    TcProfScope prof(TC_PROF_LN_ROWS, s, (double)M * 40.0);        // 16 B read, 16 B cleared, 8 B written per row
     TC_LAUNCH(ln_rows_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, row_acc, ln_rows, M, E, eps);
     TC_CHECK_LAUNCH("tc_ln_rows_finalize");
     return TC_OK;
