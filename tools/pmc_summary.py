@@ -17,7 +17,7 @@ def short(name):
     """Kernel family of a (possibly mangled) kernel name; None for kernels that are not ours."""
     m = re.search(r"(gemm128_kernel|gemm256x_kernel|gemm256_kernel|gemm_tn256x_kernel|gemm_tn256_kernel|gemm_tn_kernel|mlm_mask_kernel|attn_bwd_dq_bf16_kernel|attn_bwd_dkv_bf16_kernel|"
                   r"attn_bf16_kernel|attn_f32_kernel|layernorm_bwd_kernel|layernorm_kernel|head_bwd_kernel|"
-                  r"head_kernel|embed_bwd_kernel|embed_kernel|decode_kernel|key_mask_kernel|colsum_kernel|"
+                  r"head_rows_kernel|head_kernel|ln_rows_finalize_kernel|embed_bwd_kernel|embed_kernel|decode_kernel|key_mask_kernel|colsum_kernel|"
                   r"reduce_slabs_kernel|rope_bwd_kernel|adamw_kernel|delta_kernel|transpose_kernel)", name)
     if not m:
         return None
@@ -25,7 +25,14 @@ def short(name):
     if base.startswith("gemm1") or base.startswith("gemm2"):
         e = re.search(r"Li(\d)E", name) or re.search(r",\s*(\d)\s*>", name)
         # the profiler's demangler garbles the <__bf16, 1> instantiation into "<bool _Accum, int, E>"
-        base += "<epi=%s>" % (e.group(1) if e else ("1" if "_Accum" in name else "?"))
+        # the profiler's demangler also garbles the three-argument forms: "<bool _Accum, int, ELb, E>" is
+        # <__bf16, 3, true>, "<bool _Accum, int, E, true>" is <__bf16, 1, true>
+        if "_Accum" in name and "ELb, E" in name:
+            base += "<epi=3>+ln"
+        else:
+            base += "<epi=%s>" % (e.group(1) if e else ("1" if "_Accum" in name else "?"))
+            if "ELb1E" in name or ", true>" in name:
+                base += "+ln"          # the variant with a LayerNorm folded in
         if "IfLi" in name or "<float" in name:
             base += "f32"
     return base
