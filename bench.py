@@ -580,9 +580,9 @@ def main():
         M, E, F = B * T, 768, 3072
         per_layer = (M * E * 2 + 3 * E * E * 2 + M * 3 * E * 2) + (M * E * 2 + E * E * 2 + 2 * M * E * 4) + \
                     (M * E * 2 + F * E * 2 + M * F * 2) + (M * F * 2 + E * F * 2 + 2 * M * E * 4)
-        # folded LayerNorms: 23 of the 24 residual products also write the bf16 copy of their result
-        extra = 23 * M * E * 2 if folded else 0
-        gemm_bytes = (12 * per_layer + extra + M * E * 2 + 2 * E * E * 2 + M * 2 * E * 2) * args.steps * n_micro
+        # (with folded LayerNorms the residual stream is a pair of bf16 planes: the same 4 bytes per element
+        # in and out of the residual products as the f32 stream)
+        gemm_bytes = (12 * per_layer + M * E * 2 + 2 * E * E * 2 + M * 2 * E * 2) * args.steps * n_micro
         by_kernel = {}
         for name, bound, unit, scale, peak in (("attn", "mfma", "TFLOP/s", 1e12, PEAK_BF16_TFLOPS),
                                                ("layernorm", "hbm", "GB/s", 1e9, PEAK_HBM_GBS),
@@ -612,7 +612,7 @@ def main():
                        "codons_per_s": round(tokens_total / elapsed / 3, 1),
                        "weights": "random init N(0,0.02), 89.8M params", "parallelism": f"batch-sharded x{world}",
                        "rccl_ranks": rccl_ranks, "backend": args.backend if world > 1 else None,
-                       "layernorm": ("24 of 25 folded into the q/k/v, out-proj, fc1 and fc2 products" if folded
+                       "layernorm": ("24 of 25 folded into the q/k/v, out-proj, fc1 and fc2 products, residual stream as bf16 hi/lo planes" if folded
                                      else "separate kernels"),
                        "with_host_io_tokens_per_s": round(tokens_total / elapsed_io, 1),
                        "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3)},

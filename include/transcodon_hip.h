@@ -340,7 +340,16 @@ int tc_attn_bwd_static(int dtype, const void *qkv, int ldq, const uint64_t *key_
  * tc_ln_fold_weights   W f32 [N,K], gamma/beta f32 [K], bias f32 [N] or NULL -> Wf bf16 [N,K] =
  *                      bf16(gamma o W), s f32 [N] (sums of the ROUNDED Wf rows), c f32 [N].
  * tc_embed_fwd_ln      tc_embed_fwd that also writes xb bf16 [B*T,E] and ln_rows f32 [B*T,2] =
- *                      (rstd, -rstd * mean) of xb's rows.
+ *                      (rstd, -rstd * mean) of xb's rows; optionally x_lo bf16 [B*T,E] = bf16(x - xb), the
+ *                      remainder plane of the split residual stream (x may then be NULL).
+ * Split residual stream: tc_encoder_forward keeps x as the plane pair (xb, x_lo), x = xb + x_lo to 16 bits
+ *                      of mantissa (error 7e-6 of a row's standard deviation after 24 residual adds, 200
+ *                      times below the bf16 rounding of xb that the products see anyway), so that the residual
+ *                      products move the same bytes as with an f32 stream and the hi plane IS the operand of
+ *                      the next product: no copy is written.
+ * tc_gemm_residual_split  x += A W^T + b on the plane pair in place, plus the row sums of the new hi plane
+ *                      (row_acc as for tc_gemm_residual_ln).
+ * tc_layernorm_fwd_split  tc_layernorm_fwd reading the plane pair;  tc_split_to_f32: out[i] = hi[i] + lo[i].
  * tc_gemm_residual_ln  tc_gemm(TC_EPI_BIAS_RESIDUAL) that also writes out_bf16 [M,ldo] = bf16(out) and
  *                      adds, per row, the sum and the sum of squares of the bf16-rounded results to
  *                      row_acc (uint64 [rows,2], two's-complement integers in units of 2^-24: integer
@@ -358,8 +367,13 @@ int tc_ln_fold_weights(const float *W, const float *gamma, const float *beta, co
                        float *s_out, float *c_out, int N, int K, void *stream);
 int tc_embed_fwd_ln(const int32_t *tokens, const int32_t *species, const float *tok_table,
                     const float *species_table, float *x, uint8_t *pad_flags, int32_t *bad_index, int B, int T,
-                    int E, int vocab, int n_species, int pad_idx, void *xb, float *ln_rows, float eps,
+                    int E, int vocab, int n_species, int pad_idx, void *xb, void *x_lo, float *ln_rows, float eps,
                     void *stream);
+int tc_gemm_residual_split(int dtype, const void *A, int lda, const void *W, const float *bias, void *x_hi, void *x_lo,
+                           unsigned long long *row_acc, int ldo, int M, int N, int K, void *stream);
+int tc_layernorm_fwd_split(const void *x_hi, const void *x_lo, const float *gamma, const float *beta, float *out_f32,
+                           void *out_bf16, int M, int E, float eps, void *stream);
+int tc_split_to_f32(const void *x_hi, const void *x_lo, float *out, long n, void *stream);
 int tc_gemm_residual_ln(int dtype, const void *A, int lda, const void *W, const float *bias, const float *residual,
                         void *out, void *out_bf16, unsigned long long *row_acc, int ldo, int M, int N, int K,
                         void *stream);

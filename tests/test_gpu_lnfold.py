@@ -93,6 +93,40 @@ def test_residual_product_writes_copy_and_row_sums():
     np.testing.assert_allclose(rows[:, 1].cpu().numpy(), (-rstd * mean).cpu().numpy(), rtol=2e-5, atol=1e-6)
 
 
+def test_residual_product_on_split_planes():
+    """x = hi + lo (two bf16 planes) updated in place by tc_gemm_residual_split: the new pair represents
+    the f32 result of the plain residual product on the same x to 16 bits of mantissa, hi is its bf16
+    rounding exactly, and the row sums are those of the new hi plane."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn(M, E, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(E, E, generator=g) * 0.03).to(DEV, torch.bfloat16)
+    bias = (0.1 * torch.randn(E, generator=g)).to(DEV)
+    x = (torch.randn(M, E, generator=g) * 3 + 1.0).to(DEV)
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    x16 = hi.float() + lo.float()                                     # what the planes hold
+    want = ops.gemm(a, w, bias, epilogue=_lib.EPI_BIAS_RESIDUAL, residual=x16)
+    acc = torch.zeros(M, 2, dtype=torch.int64, device=DEV)
+    _lib.check(lib.tc_gemm_residual_split(_lib.TC_BF16, a.data_ptr(), E, w.data_ptr(), bias.data_ptr(), hi.data_ptr(),
+                                          lo.data_ptr(), acc.data_ptr(), E, M, E, E, _stream()), "tc_gemm_residual_split")
+    assert torch.equal(hi, want.to(torch.bfloat16))
+    got = hi.float() + lo.float()
+    rel = ((got - want).abs() / want.abs().clamp_min(1e-3)).max()
+    assert float(rel) <= 2.0 ** -15, float(rel)
+    s1 = acc[:, 0].double() / 2 ** 24
+    np.testing.assert_allclose(s1.cpu().numpy(), hi.double().sum(1).cpu().numpy(), rtol=0, atol=2e-3)
+    out = torch.empty(M, E, device=DEV)
+    _lib.check(lib.tc_split_to_f32(hi.data_ptr(), lo.data_ptr(), out.data_ptr(), M * E, _stream()), "tc_split_to_f32")
+    assert torch.equal(out, got)
+    gamma = (1 + 0.1 * torch.randn(E, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(E, generator=g)).to(DEV)
+    ln = torch.empty(M, E, device=DEV)
+    _lib.check(lib.tc_layernorm_fwd_split(hi.data_ptr(), lo.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ln.data_ptr(),
+                                          None, M, E, 1e-5, _stream()), "tc_layernorm_fwd_split")
+    assert torch.equal(ln, ops.layernorm(got, gamma, beta, 1e-5))
+
+
 def _rows_of(xb):
     x = xb.double()
     rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)
@@ -171,15 +205,17 @@ def test_embed_with_row_statistics():
     st = torch.randn(16, E, generator=g).to(DEV)
     x = torch.empty(B * Tn, E, device=DEV)
     xb = torch.empty(B * Tn, E, dtype=torch.bfloat16, device=DEV)
+    xlo = torch.empty(B * Tn, E, dtype=torch.bfloat16, device=DEV)
     rows = torch.empty(B * Tn, 2, device=DEV)
     pad = torch.empty(B * Tn, dtype=torch.uint8, device=DEV)
     tok_d, sp_d = tok.to(DEV), sp.to(DEV)
     _lib.check(lib.tc_embed_fwd_ln(tok_d.data_ptr(), sp_d.data_ptr(), tt.data_ptr(), st.data_ptr(),
                                    x.data_ptr(), pad.data_ptr(), None, B, Tn, E, 10, 16, 1, xb.data_ptr(),
-                                   rows.data_ptr(), 1e-5, _stream()), "tc_embed_fwd_ln")
+                                   xlo.data_ptr(), rows.data_ptr(), 1e-5, _stream()), "tc_embed_fwd_ln")
     ref = (tt[tok.long().to(DEV)] + st[sp.long().to(DEV)][:, None, :]) * (tok.to(DEV) != 1)[..., None]
     assert torch.equal(x.view(B, Tn, E), ref)
     assert torch.equal(xb, x.to(torch.bfloat16))
+    assert torch.equal(xlo, (x - xb.float()).to(torch.bfloat16))
     v = xb.double()
     rstd = 1.0 / torch.sqrt(v.var(1, unbiased=False) + 1e-5)
     np.testing.assert_allclose(rows[:, 0].cpu().numpy(), rstd.cpu().numpy(), rtol=2e-5)

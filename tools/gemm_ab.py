@@ -25,6 +25,9 @@ def load(path):
     res, args = _lib._SIGNATURES["tc_gemm"]
     lib.tc_gemm.restype, lib.tc_gemm.argtypes = res, args
     lib.tc_last_error.restype = C.c_char_p
+    if hasattr(lib, "tc_gemm_residual_split"):
+        res, args = _lib._SIGNATURES["tc_gemm_residual_split"]
+        lib.tc_gemm_residual_split.restype, lib.tc_gemm_residual_split.argtypes = res, args
     if hasattr(lib, "tc_gemm_residual_ln"):
         res, args = _lib._SIGNATURES["tc_gemm_residual_ln"]
         lib.tc_gemm_residual_ln.restype, lib.tc_gemm_residual_ln.argtypes = res, args
@@ -59,7 +62,12 @@ def main():
               "fc2": (mid, F + 64, E, F, _lib.EPI_BIAS_RESIDUAL, E, True),
               # the new build also writes the bf16 copy and the row sums of a folded LayerNorm
               "out_ln": (x, E, E, E, _lib.EPI_BIAS_RESIDUAL, E, True),
-              "fc2_ln": (mid, F + 64, E, F, _lib.EPI_BIAS_RESIDUAL, E, True)}
+              "fc2_ln": (mid, F + 64, E, F, _lib.EPI_BIAS_RESIDUAL, E, True),
+              # the new build keeps the residual stream as two bf16 planes, updated in place
+              "out_split": (x, E, E, E, _lib.EPI_BIAS_RESIDUAL, E, True),
+              "fc2_split": (mid, F + 64, E, F, _lib.EPI_BIAS_RESIDUAL, E, True)}
+    plane_hi = torch.randn(M, E, device=dev, generator=g).bfloat16()
+    plane_lo = (torch.randn(M, E, device=dev, generator=g) * 1e-3).bfloat16()
     copy16 = torch.empty(M, E, device=dev, dtype=torch.bfloat16)
     row_acc = torch.zeros(M, 2, device=dev, dtype=torch.int64)
     for name in a.only.split(","):
@@ -72,6 +80,11 @@ def main():
             if name.endswith("_ln") and k == "new":
                 rc = libs[k].tc_gemm_residual_ln(1, A.data_ptr(), lda, w.data_ptr(), b.data_ptr(), res.data_ptr(),
                                                  outs[k].data_ptr(), copy16.data_ptr(), row_acc.data_ptr(), ldo, M, N, K, strm)
+                assert rc == 0, libs[k].tc_last_error()
+                return
+            if name.endswith("_split") and k == "new":
+                rc = libs[k].tc_gemm_residual_split(1, A.data_ptr(), lda, w.data_ptr(), b.data_ptr(), plane_hi.data_ptr(),
+                                                    plane_lo.data_ptr(), row_acc.data_ptr(), ldo, M, N, K, strm)
                 assert rc == 0, libs[k].tc_last_error()
                 return
             rc = libs[k].tc_gemm(1, epi, A.data_ptr(), lda, w.data_ptr(), b.data_ptr(), res.data_ptr() if f32 else None,

@@ -65,7 +65,10 @@ _SIGNATURES = {
     "tc_version": (C.c_int, []),
     "tc_last_error": (C.c_char_p, []),
     "tc_embed_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
-    "tc_embed_fwd_ln": (C.c_int, [vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 6 + [vp, vp, C.c_float, vp]),
+    "tc_embed_fwd_ln": (C.c_int, [vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 6 + [vp, vp, vp, C.c_float, vp]),
+    "tc_gemm_residual_split": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "tc_layernorm_fwd_split": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
+    "tc_split_to_f32": (C.c_int, [vp, vp, vp, C.c_long, vp]),
     "tc_ln_rows_finalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "tc_ln_fold_weights": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "tc_gemm_ln": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -107,9 +107,15 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
         return tc_layernorm_fwd(w.x, g, b, bf ? extra_f32 : static_cast<float *>(w.h),
                                 bf ? w.h : nullptr, M, E, d->ln_eps, stream);
     };
+    void *x_lo = w.x;          // folded forward: the residual stream is the plane pair (w.xb, x_lo), no f32 copy exists
+    bool fold = false;
     auto save_rep = [&](int layer) -> int {
         for (int i = 0; i < n_rep; ++i)
             if (rep_layer[i] == layer) {
+                if (fold) {
+                    TC_TRY(tc_split_to_f32(w.xb, x_lo, rep_out[i], (long)M * E, stream));
+                    continue;
+                }
                 hipError_t e = hipMemcpyAsync(rep_out[i], w.x, (size_t)M * E * 4, hipMemcpyDeviceToDevice, s);
                 if (e != hipSuccess) {
                     tc_set_error("tc_encoder_forward: representation copy: %s", hipGetErrorString(e));
@@ -121,7 +127,7 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
 
     // Folded LayerNorms: when every layer carries the folded weights and the batch is large enough
     // for the alternating large-tile kernels, no LayerNorm kernel runs inside the layers.
-    bool fold = bf && tc_ln_fold_supported(dt, B, T, E, F) != 0;
+    fold = bf && tc_ln_fold_supported(dt, B, T, E, F) != 0;
     for (int l = 0; l < d->num_layers && fold; ++l) {
         const tc_layer_weights &lw = d->layers[l];
         fold = lw.w_qkv_ln && lw.c_qkv_ln && lw.s_qkv_ln && lw.w_fc1_ln && lw.c_fc1_ln && lw.s_fc1_ln;
@@ -132,8 +138,8 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
             tc_set_error("tc_encoder_forward: clearing the row accumulators: %s", hipGetErrorString(e));
             return TC_ELAUNCH;
         }
-        TC_TRY(tc_embed_fwd_ln(tokens, species, d->tok_table, d->species_table, w.x, w.pad, status, B, T, E, d->vocab,
-                               d->n_species, d->pad_idx, w.xb, w.ln_rows, d->ln_eps, stream));
+        TC_TRY(tc_embed_fwd_ln(tokens, species, d->tok_table, d->species_table, nullptr, w.pad, status, B, T, E, d->vocab,
+                               d->n_species, d->pad_idx, w.xb, x_lo, w.ln_rows, d->ln_eps, stream));
     } else {
         TC_TRY(tc_embed_fwd(tokens, species, d->tok_table, d->species_table, w.x, w.pad, status, B, T, E,
                             d->vocab, d->n_species, d->pad_idx, stream));
@@ -153,16 +159,13 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
             TC_TRY(tc_gemm_ln(dt, TC_EPI_QKV_ROPE, w.xb, E, lw.w_qkv_ln, lw.c_qkv_ln, lw.s_qkv_ln, w.ln_rows, w.qkv,
                               3 * E, M, 3 * E, E, 0.125f, lw.rope_cos, lw.rope_sin, T, 64, stream));
             TC_TRY(tc_attn_fwd(dt, w.qkv, 3 * E, w.words, w.h, B, T, d->H, 64, stream));
-            TC_TRY(tc_gemm_residual_ln(dt, w.h, E, lw.w_o, lw.b_o, w.x, w.x, w.xb, w.row_acc, E, M, E, E, stream));
+            TC_TRY(tc_gemm_residual_split(dt, w.h, E, lw.w_o, lw.b_o, w.xb, x_lo, w.row_acc, E, M, E, E, stream));
             TC_TRY(tc_ln_rows_finalize(w.row_acc, w.ln_rows, M, E, d->ln_eps, stream));
             TC_TRY(tc_gemm_ln(dt, TC_EPI_BIAS_GELU, w.xb, E, lw.w_fc1_ln, lw.c_fc1_ln, lw.s_fc1_ln, w.ln_rows, w.mid,
                               w.ld_mid, M, F, E, 0.f, nullptr, nullptr, 0, 0, stream));
-            if (last) {
-                TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.x, w.x, E, M, E, F, 0.f,
-                               nullptr, nullptr, 0, 0, stream));
-            } else {
-                TC_TRY(tc_gemm_residual_ln(dt, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.x, w.x, w.xb, w.row_acc, E, M, E,
-                                           F, stream));
+            TC_TRY(tc_gemm_residual_split(dt, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.xb, x_lo, w.row_acc, E, M, E, F,
+                                          stream));
+            if (!last) {
                 TC_TRY(tc_ln_rows_finalize(w.row_acc, w.ln_rows, M, E, d->ln_eps, stream));
                 TC_TRY(save_rep(l + 1));
             }
@@ -183,7 +186,9 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
     }
 
     // final LayerNorm; the f32 copy doubles as representations[num_layers]
-    if (bf) {
+    if (fold) {
+        TC_TRY(tc_layernorm_fwd_split(w.xb, x_lo, d->lnf_g, d->lnf_b, rep_last, w.h, M, E, d->ln_eps, stream));
+    } else if (bf) {
         TC_TRY(tc_layernorm_fwd(w.x, d->lnf_g, d->lnf_b, rep_last, w.h, M, E, d->ln_eps, stream));
     } else {
         TC_TRY(tc_layernorm_fwd(w.x, d->lnf_g, d->lnf_b, static_cast<float *>(w.h), nullptr, M, E, d->ln_eps, stream));

@@ -50,6 +50,11 @@ struct GemmParams {
     const float *ln_s;
     const float *ln_rows;
     unsigned long long *row_acc;
+    // producer in split form (gemm256x_kernel<bf16, TC_EPI_BIAS_RESIDUAL, FOLD>): the residual stream is a pair
+    // of bf16 planes x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 bits of mantissa); `residual` / `out2`
+    // point to the hi plane, res_lo / out_lo to the lo plane; no f32 result is written
+    const char *res_lo;
+    char *out_lo;
     long lda_bytes, ldw_bytes;
     long slab_elems;       // split-K: f32 elements between the partial outputs of two splits
     int splits;            // split-K factor of the small-tile kernel (1 = off)
@@ -423,10 +428,31 @@ template <int LAY> __device__ __forceinline__ constexpr int ni_off(int ni) {
 
 // Accumulators of one 128 x 64 wave tile start at bias (+ residual): no bias registers are held
 // through the k-loop.  acc[ni][mi] = D[n][m] tiles of 16 x 16.
-template <typename T, int EPI, int LAY = 0, int MI0 = 0, int MI1 = 8, int NI0 = 0, int NI1 = 4>
+template <typename T, int EPI, int LAY = 0, int MI0 = 0, int MI1 = 8, int NI0 = 0, int NI1 = 4, bool SPLIT = false>
 __device__ __forceinline__ void init_acc256(const GemmParams &p, f32x4 (&acc)[4][8], int mrow0, int ncol0) {
     constexpr bool kPreloadResidual = EPI == TC_EPI_BIAS_RESIDUAL && sizeof(T) == 2;
-    {
+    if constexpr (SPLIT) {
+        // residual stream as two bf16 planes: the lane's 8 consecutive columns of a pair of accumulator
+        // tiles are one 16-byte load from each plane
+        static_assert(kPreloadResidual && LAY == 2, "split residual planes: bf16 large tile, interleaved columns");
+        const char *hi_base = reinterpret_cast<const char *>(p.residual);
+#pragma unroll
+        for (int ni = NI0; ni < NI1; ni += 2) {
+            const f32x4 b0 = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + ncol0 + ni_off<LAY>(ni)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 b1 = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + ncol0 + ni_off<LAY>(ni + 1)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mi = MI0; mi < MI1; ++mi) {
+                const int m = mrow0 + mi_off<LAY>(mi);
+                const long at = ((long)(m < p.M ? m : p.M - 1) * p.ldo + ncol0 + ni_off<LAY>(ni)) * 2;
+                const u32x4 h = *reinterpret_cast<const u32x4 *>(hi_base + at);
+                const u32x4 l = *reinterpret_cast<const u32x4 *>(p.res_lo + at);
+                acc[ni][mi] = f32x4{tc_bf16_lo(h[0]) + tc_bf16_lo(l[0]), tc_bf16_hi(h[0]) + tc_bf16_hi(l[0]),
+                                    tc_bf16_lo(h[1]) + tc_bf16_lo(l[1]), tc_bf16_hi(h[1]) + tc_bf16_hi(l[1])} + b0;
+                acc[ni + 1][mi] = f32x4{tc_bf16_lo(h[2]) + tc_bf16_lo(l[2]), tc_bf16_hi(h[2]) + tc_bf16_hi(l[2]),
+                                        tc_bf16_lo(h[3]) + tc_bf16_lo(l[3]), tc_bf16_hi(h[3]) + tc_bf16_hi(l[3])} + b1;
+            }
+        }
+    } else {
         f32x4 bias[4];
 #pragma unroll
         for (int ni = NI0; ni < NI1; ++ni)
@@ -448,9 +474,29 @@ __device__ __forceinline__ void init_acc256(const GemmParams &p, f32x4 (&acc)[4]
 
 }
 
+// Row sums for a folded LayerNorm: sum and sum of squares of a pair of bf16 values, one dot-product
+// instruction each (products of bf16 values are exact in f32).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ void row_sums(uint32_t pair, float &s1, float &s2) {
+    const bf16x2_t w = __builtin_bit_cast(bf16x2_t, pair), ones = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);
+    s1 = __builtin_amdgcn_fdot2_f32_bf16(w, ones, s1, false);
+    s2 = __builtin_amdgcn_fdot2_f32_bf16(w, w, s2, false);
+}
+// The four lanes that share a row (16 lanes apart) add up; lane group 0 leaves the f32 pair in the
+// plane of this column wave (row = wave row group * 64 + row block offset + lane row).
+__device__ __forceinline__ void put_row_sums(char *planes, int wm, int wn, int block_off, int frow, int fgrp, float s1,
+                                             float s2) {
+    s1 += __shfl_xor(s1, 16, 64);
+    s2 += __shfl_xor(s2, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (fgrp == 0) *reinterpret_cast<f32x2 *>(planes + (wn * 256 + wm * 64 + block_off + frow) * 8) = f32x2{s1, s2};
+}
+
 // Epilogue of one wave tile.  Phase 1: arithmetic in place (its table loads are not queued
 // behind any store); phase 2: all stores.
-template <typename T, int EPI, int LAY = 0, int MI0 = 0, int MI1 = 8, int NI0 = 0, int NI1 = 4, bool LDSX = false>
+template <typename T, int EPI, int LAY = 0, int MI0 = 0, int MI1 = 8, int NI0 = 0, int NI1 = 4, bool LDSX = false,
+          bool SPLIT = false>
 __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4][8], int tm, int tn, int mrow0,
                                             int ncol0, int wm, int wn, int frow, int fgrp,
                                             const char *bias_lds = nullptr, const char *rope_lds = nullptr,
@@ -711,44 +757,23 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
             for (int e = 0; e < 4; ++e) o[e] = (unsigned)__builtin_amdgcn_ds_bpermute(pull, (int)w[e]);
             return o;
         };
-        if constexpr (EPI == TC_EPI_BIAS_RESIDUAL && MI0 == 0 && MI1 == 8 && NI0 == 0 && NI1 == 4) {
+        if constexpr (EPI == TC_EPI_BIAS_RESIDUAL && MI0 == 0 && MI1 == 8 && NI0 == 0 && NI1 == 4 && !SPLIT) {
             if (stat_lds) {
                 // Row statistics for the LayerNorm folded into the next product: sum and sum of squares of
                 // the bf16-rounded results (the values the next product multiplies).  Per wave: its 64
-                // columns of 128 rows; the four lanes that share a row add up, lane group 0 leaves the
-                // pair as two int64 in units of 2^-24 (an exact image of the f32 partial) in the plane of
-                // this column wave; after a barrier every thread adds one (row, statistic) of the four
-                // planes to the global accumulator.  Integer adds: the result does not depend on order.
+                // columns of 128 rows; the four lanes that share a row add up and lane group 0 leaves the
+                // f32 pair in the plane of this column wave.  The kernel adds the four planes of a tile to
+                // the global accumulators later (flush_row_sums), as integers.
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) {
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) {
                         const f32x4 v = acc[ni][mi];
-                        const uint32_t w0 = tc_pack_bf16(v[0], v[1]), w1 = tc_pack_bf16(v[2], v[3]);
-                        const float a = tc_bf16_lo(w0), b = tc_bf16_hi(w0), c = tc_bf16_lo(w1), d = tc_bf16_hi(w1);
-                        s1 += (a + b) + (c + d);
-                        s2 += (a * a + b * b) + (c * c + d * d);
+                        row_sums(tc_pack_bf16(v[0], v[1]), s1, s2);
+                        row_sums(tc_pack_bf16(v[2], v[3]), s1, s2);
                     }
-                    s1 += __shfl_xor(s1, 16, 64);
-                    s2 += __shfl_xor(s2, 16, 64);
-                    s1 += __shfl_xor(s1, 32, 64);
-                    s2 += __shfl_xor(s2, 32, 64);
-                    if (fgrp == 0) {
-                        long long q[2] = {(long long)(s1 * 16777216.f), (long long)(s2 * 16777216.f)};
-                        const int row = wm * 64 + mi_off<LAY>(mi) + frow;            // row of the tile
-                        *reinterpret_cast<u32x4 *>(stat_lds + (wn * 256 + row) * 16) = __builtin_bit_cast(u32x4, q);
-                    }
-                }
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                __builtin_amdgcn_s_barrier();
-                {
-                    const int t = threadIdx.x, row = t >> 1, which = t & 1;
-                    unsigned long long sum = 0;
-#pragma unroll
-                    for (int pl = 0; pl < 4; ++pl)
-                        sum += *reinterpret_cast<const unsigned long long *>(stat_lds + (pl * 256 + row) * 16 + which * 8);
-                    if (tm * BM + row < p.M) atomicAdd(p.row_acc + 2L * (tm * BM + row) + which, sum);
+                    put_row_sums(stat_lds, wm, wn, mi_off<LAY>(mi), frow, fgrp, s1, s2);
                 }
             }
         }
@@ -768,6 +793,32 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
                     w = exchange(w);
                     if (m < p.M) *reinterpret_cast<u32x4 *>(p.out + (orow + ni_off<LAY>(ni)) * 2) = w;
                 }
+            } else if constexpr (SPLIT) {
+                // result as two bf16 planes, hi = bf16(v), lo = bf16(v - hi): one 16-byte store each
+                static_assert(LAY == 2 && EPI == TC_EPI_BIAS_RESIDUAL, "split planes: residual epilogue, interleaved columns");
+                float s1 = 0.f, s2 = 0.f;               // row sums of the hi plane (this lane's own row, before the exchange)
+#pragma unroll
+                for (int ni = NI0; ni < NI1; ni += 2) {
+                    const f32x4 v = acc[ni][mi], v2 = acc[ni + 1][mi];
+                    u32x4 h, l;
+                    h[0] = tc_pack_bf16(v[0], v[1]);
+                    h[1] = tc_pack_bf16(v[2], v[3]);
+                    h[2] = tc_pack_bf16(v2[0], v2[1]);
+                    h[3] = tc_pack_bf16(v2[2], v2[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) row_sums(h[e], s1, s2);
+                    l[0] = tc_pack_bf16(v[0] - tc_bf16_lo(h[0]), v[1] - tc_bf16_hi(h[0]));
+                    l[1] = tc_pack_bf16(v[2] - tc_bf16_lo(h[1]), v[3] - tc_bf16_hi(h[1]));
+                    l[2] = tc_pack_bf16(v2[0] - tc_bf16_lo(h[2]), v2[1] - tc_bf16_hi(h[2]));
+                    l[3] = tc_pack_bf16(v2[2] - tc_bf16_lo(h[3]), v2[3] - tc_bf16_hi(h[3]));
+                    h = exchange(h);
+                    l = exchange(l);
+                    if (m < p.M) {
+                        *reinterpret_cast<u32x4 *>(p.out2 + (orow + ni_off<LAY>(ni)) * 2) = h;
+                        *reinterpret_cast<u32x4 *>(p.out_lo + (orow + ni_off<LAY>(ni)) * 2) = l;
+                    }
+                }
+                if (stat_lds) put_row_sums(stat_lds, wm, wn, mi_off<LAY>(mi), frow, fgrp, s1, s2);
             } else {
                 static_assert(kF32Out, "bf16 results use the interleaved column order");
 #pragma unroll
@@ -1034,6 +1085,19 @@ constexpr int ROWS_OFF = STEP_OFF + 8 * 512;
 constexpr int LDS_BYTES = ROWS_OFF + 2 * 1024;  // 158 KiB
 }  // namespace k256x
 
+// Adds a finished tile's row sums to the global accumulators: thread t takes (row t >> 1, statistic
+// t & 1), converts the four column waves' f32 partials to integers in units of 2^-24 (an exact image
+// of each) and adds their sum with one 64-bit atomic.  Integer adds: the result does not depend on
+// the order in which the column tiles of a row arrive.
+__device__ __forceinline__ void flush_row_sums(const GemmParams &p, const char *planes, int tm) {
+    const int t = threadIdx.x, row = t >> 1, which = t & 1;
+    long long sum = 0;
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl)
+        sum += (long long)(*reinterpret_cast<const float *>(planes + (pl * 256 + row) * 8 + which * 4) * 16777216.f);
+    if (tm * 256 + row < p.M) atomicAdd(p.row_acc + 2L * (tm * 256 + row) + which, (unsigned long long)sum);
+}
+
 constexpr bool piecewise_epilogue(int epi) {
     return epi == TC_EPI_BIAS || epi == TC_EPI_BIAS_GELU || epi == TC_EPI_BIAS_GELU_SAVE ||
            epi == TC_EPI_PLAIN_F32 || epi == TC_EPI_QKV_ROPE;
@@ -1143,8 +1207,11 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     char *const bias_slot = smem + BIAS_OFF + wid * 1024;
     char *const rope_slot = smem + ROPE_OFF + wid * 2048;
     char *const step_slot = smem + STEP_OFF + wid * 512;
-    constexpr bool ln_fold = FOLD;                 // a LayerNorm folded into this product (p.ln_rows, p.ln_s)
-    static_assert(!FOLD || EPI == TC_EPI_QKV_ROPE || EPI == TC_EPI_BIAS_GELU, "no folded form of this epilogue");
+    constexpr bool ln_fold = FOLD && EPI != TC_EPI_BIAS_RESIDUAL;   // a LayerNorm folded into this product (p.ln_rows, p.ln_s)
+    static_assert(!FOLD || EPI == TC_EPI_QKV_ROPE || EPI == TC_EPI_BIAS_GELU || EPI == TC_EPI_BIAS_RESIDUAL,
+                  "no folded form of this epilogue");
+    // FOLD on the residual epilogue: the producer side in split form (residual stream as bf16 planes)
+    constexpr bool kSplit = FOLD && EPI == TC_EPI_BIAS_RESIDUAL;
     char *const rows_slot = smem + ROWS_OFF + wr * 1024;
     auto stage_epilogue_inputs = [&](int tm, int tn) {
         int L = lane;
@@ -1292,7 +1359,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         const int mrow0 = tm * BM + wr * 64 + frow;           // + mi_off<1>(mi)
         const int ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);     // + ni_off<kLay>(ni)
         if constexpr (!kPiece) {
-            init_acc256<T, EPI, kLay>(p, acc, mrow0, ncol0);
+            init_acc256<T, EPI, kLay, 0, 8, 0, 4, kSplit>(p, acc, mrow0, ncol0);
             if (wr == 1) TC_XBAR();
         }
         const bool prev_full = kPiece && t > 0 && ptm * BM + BM <= p.M;
@@ -1444,9 +1511,16 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         if constexpr (!kPiece) {
             if (wr == 0) TC_XBAR();               // row group 1's last phase
             TC_STAMP(e0);
-            epilogue256<T, EPI, kLay, 0, 8, 0, 4, kGeluTable>(p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, nullptr,
+            // row sums (folded LayerNorm, producer side): the planes of tile t-1 are flushed here, one
+            // tile late, so that no barrier is needed between the waves' plane writes and the flush
+            // (the k-loop's barriers lie in between); two sets of planes alternate
+            char *const stat_planes = smem + BIAS_OFF + (t & 1) * 8192;
+            if constexpr (EPI == TC_EPI_BIAS_RESIDUAL) {
+                if (p.row_acc && t > 0) flush_row_sums(p, smem + BIAS_OFF + ((t - 1) & 1) * 8192, ptm);
+            }
+            epilogue256<T, EPI, kLay, 0, 8, 0, 4, kGeluTable, kSplit>(p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, nullptr,
                                                               smem + ROPE_OFF, nullptr, nullptr,
-                                                              p.row_acc ? smem + BIAS_OFF : nullptr);
+                                                              p.row_acc ? stat_planes : nullptr);
 #ifdef TC_GEMM_STAMPS
             TC_STAMP(e1);
             c_epi += e1 - e0;
@@ -1476,6 +1550,13 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     }
 #endif
     if constexpr (kPiece) finish_tile(ptm, ptn);
+    if constexpr (EPI == TC_EPI_BIAS_RESIDUAL) {
+        if (p.row_acc) {                          // the last tile's row sums
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            flush_row_sums(p, smem + BIAS_OFF + ((my_count - 1) & 1) * 8192, ptm);
+        }
+    }
 }
 
 // =============================================================================================
@@ -1541,8 +1622,8 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
         // sequence boundary inside a 256-row tile, head dimension 64
         bool use_alt = alt != 0;
         if (EPI == TC_EPI_QKV_ROPE && (p.T % 256 != 0 || p.head_dim != 64 || p.pos)) use_alt = false;
-        constexpr bool kHasFold = EPI == TC_EPI_QKV_ROPE || EPI == TC_EPI_BIAS_GELU;
-        if (use_alt && kHasFold && p.ln_rows) {
+        constexpr bool kHasFold = EPI == TC_EPI_QKV_ROPE || EPI == TC_EPI_BIAS_GELU || EPI == TC_EPI_BIAS_RESIDUAL;
+        if (use_alt && kHasFold && (EPI == TC_EPI_BIAS_RESIDUAL ? p.res_lo != nullptr : p.ln_rows != nullptr)) {
             if constexpr (kHasFold) {
                 static bool attr_set_f = false;
                 if (!attr_set_f) {
@@ -1618,7 +1699,7 @@ static int gemm_impl(int dtype, int epilogue, const void *A, int lda, const void
                      const float *residual, const void *aux, void *out, void *out2, int ldo, int M, int N,
                      int K, int splits, float q_scale, const float *rope_cos, const float *rope_sin, int T,
                      int head_dim, void *stream, const int32_t *pos = nullptr, const float *ln_s = nullptr,
-                     const float *ln_rows = nullptr, unsigned long long *row_acc = nullptr) {
+                     const float *ln_rows = nullptr, unsigned long long *row_acc = nullptr, void *split_lo = nullptr) {
     TC_REQUIRE(dtype == TC_BF16 || dtype == TC_F32, "tc_gemm: bad dtype %d", dtype);
     const int esz = dtype == TC_BF16 ? 2 : 4;
     const int kt = 128 / esz;
@@ -1688,6 +1769,10 @@ static int gemm_impl(int dtype, int epilogue, const void *A, int lda, const void
         if (force == -2) { const char *e = getenv("TC_GEMM_TILE"); force = e ? atoi(e) : -1; }
         if (force == 128) big = false;
     }
+    if (split_lo) {
+        p.res_lo = static_cast<const char *>(split_lo);
+        p.out_lo = static_cast<char *>(split_lo);
+    }
     if (ln_s || ln_rows || row_acc) {
         // the folded LayerNorm lives in the alternating large-tile kernel's epilogues only
         bool ok = big && alt_schedule_enabled();
@@ -1748,6 +1833,18 @@ extern "C" int tc_gemm_residual_ln(int dtype, const void *A, int lda, const void
                "tc_gemm_residual_ln: needs the bf16 copy and the row accumulators");
     return gemm_impl(dtype, TC_EPI_BIAS_RESIDUAL, A, lda, W, bias, residual, nullptr, out, out_bf16, ldo, M, N, K, 1, 0.f,
                      nullptr, nullptr, 0, 0, stream, nullptr, nullptr, nullptr, row_acc);
+}
+
+// The same with the residual stream held as two bf16 planes (x = hi + lo), updated in place: reads the
+// planes as the residual, writes the new planes (the hi plane is what the next folded product multiplies)
+// and the row sums of the new hi plane.  No f32 result exists.
+extern "C" int tc_gemm_residual_split(int dtype, const void *A, int lda, const void *W, const float *bias, void *x_hi,
+                                      void *x_lo, unsigned long long *row_acc, int ldo, int M, int N, int K,
+                                      void *stream) {
+    TC_REQUIRE(x_hi && x_lo && row_acc && tc_aligned16(x_hi) && tc_aligned16(x_lo) && tc_aligned16(row_acc),
+               "tc_gemm_residual_split: needs both planes and the row accumulators, 16-byte aligned");
+    return gemm_impl(dtype, TC_EPI_BIAS_RESIDUAL, A, lda, W, bias, static_cast<const float *>(x_hi), nullptr, x_hi, x_hi,
+                     ldo, M, N, K, 1, 0.f, nullptr, nullptr, 0, 0, stream, nullptr, nullptr, nullptr, row_acc, x_lo);
 }
 
 // 1 when a forward of M = B*T rows can run with its LayerNorms folded into the products: every

@@ -15,9 +15,10 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t *__restrict__ 
                                                     int32_t *bad_index, int M, int T, int E,
                                                     int vocab, int n_species, int pad_idx,
                                                     uint16_t *__restrict__ xb, float *__restrict__ ln_rows,
-                                                    float eps) {
+                                                    float eps, uint16_t *__restrict__ x_lo) {
     // xb / ln_rows (optional, together): bf16 copy of the row and (rstd, -rstd * mean) of that copy,
-    // for a first LayerNorm folded into the product that follows
+    // for a first LayerNorm folded into the product that follows.  x_lo (optional, with xb): the
+    // remainder plane bf16(x - xb) of the split residual stream; x itself may then be NULL.
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -32,8 +33,9 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t *__restrict__ 
     float *dst = x + (long)row * E;
     if (pad || bad) {
         for (int c = lane * 4; c < E; c += 256) {
-            *reinterpret_cast<f32x4 *>(dst + c) = f32x4{0, 0, 0, 0};
+            if (x) *reinterpret_cast<f32x4 *>(dst + c) = f32x4{0, 0, 0, 0};
             if (xb) *reinterpret_cast<u32x2 *>(xb + (long)row * E + c) = u32x2{0, 0};
+            if (x_lo) *reinterpret_cast<u32x2 *>(x_lo + (long)row * E + c) = u32x2{0, 0};
         }
         if (ln_rows && lane == 0) *reinterpret_cast<f32x2 *>(ln_rows + 2L * row) = f32x2{rsqrtf(eps), 0.f};
         return;
@@ -45,13 +47,19 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t *__restrict__ 
         const f32x4 va = *reinterpret_cast<const f32x4 *>(a + c);
         const f32x4 vb = *reinterpret_cast<const f32x4 *>(b + c);
         const f32x4 v = va + vb;
-        *reinterpret_cast<f32x4 *>(dst + c) = v;
+        if (x) *reinterpret_cast<f32x4 *>(dst + c) = v;
         if (xb) {
             u32x2 w;
             w[0] = tc_pack_bf16(v[0], v[1]);
             w[1] = tc_pack_bf16(v[2], v[3]);
             *reinterpret_cast<u32x2 *>(xb + (long)row * E + c) = w;
             const float p = tc_bf16_lo(w[0]), q = tc_bf16_hi(w[0]), r = tc_bf16_lo(w[1]), t = tc_bf16_hi(w[1]);
+            if (x_lo) {
+                u32x2 l;
+                l[0] = tc_pack_bf16(v[0] - p, v[1] - q);
+                l[1] = tc_pack_bf16(v[2] - r, v[3] - t);
+                *reinterpret_cast<u32x2 *>(x_lo + (long)row * E + c) = l;
+            }
             s1 += (p + q) + (r + t);
             s2 += (p * p + q * q) + (r * r + t * t);
         }
@@ -86,6 +94,16 @@ __global__ __launch_bounds__(256) void ln_rows_finalize_kernel(unsigned long lon
     var = var > 0.0 ? var : 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     *reinterpret_cast<f32x2 *>(ln_rows + 2L * row) = f32x2{rstd, (float)(-(double)rstd * mean)};
+}
+
+// x = hi + lo of the split residual stream as f32 (representations of inner layers)
+__global__ __launch_bounds__(256) void split_to_f32_kernel(const uint16_t *__restrict__ hi, const uint16_t *__restrict__ lo,
+                                                           float *__restrict__ out, long n4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const u32x2 h = *reinterpret_cast<const u32x2 *>(hi + 4 * i), l = *reinterpret_cast<const u32x2 *>(lo + 4 * i);
+        *reinterpret_cast<f32x4 *>(out + 4 * i) = f32x4{tc_bf16_lo(h[0]) + tc_bf16_lo(l[0]), tc_bf16_hi(h[0]) + tc_bf16_hi(l[0]),
+                                                        tc_bf16_lo(h[1]) + tc_bf16_lo(l[1]), tc_bf16_hi(h[1]) + tc_bf16_hi(l[1])};
+    }
 }
 
 // One wave per output feature n: Wf[n,:] = bf16(gamma o W[n,:]), s[n] = sum_k Wf[n,k] (of the rounded
@@ -126,7 +144,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
                                                         const float *__restrict__ gamma,
                                                         const float *__restrict__ beta,
                                                         float *out_f32, uint16_t *out_bf16, int M,
-                                                        int E, float eps) {
+                                                        int E, float eps, const uint16_t *__restrict__ x_hi,
+                                                        const uint16_t *__restrict__ x_lo) {
+    // x_hi / x_lo (instead of x): the row as two bf16 planes, x = hi + lo
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -136,7 +156,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int col = c * 256 + lane * 4;
-        v[c] = col < E ? *reinterpret_cast<const f32x4 *>(src + col) : f32x4{0, 0, 0, 0};
+        if (col >= E) {
+            v[c] = f32x4{0, 0, 0, 0};
+        } else if (x_hi) {
+            const u32x2 h = *reinterpret_cast<const u32x2 *>(x_hi + (long)row * E + col);
+            const u32x2 l = *reinterpret_cast<const u32x2 *>(x_lo + (long)row * E + col);
+            v[c] = f32x4{tc_bf16_lo(h[0]) + tc_bf16_lo(l[0]), tc_bf16_hi(h[0]) + tc_bf16_hi(l[0]),
+                         tc_bf16_lo(h[1]) + tc_bf16_lo(l[1]), tc_bf16_hi(h[1]) + tc_bf16_hi(l[1])};
+        } else {
+            v[c] = *reinterpret_cast<const f32x4 *>(src + col);
+        }
         s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
     }
     const float mean = tc_wave_sum(s) / (float)E;
@@ -597,8 +626,9 @@ extern "C" int tc_mean_pool_packed(const float *rep, const int32_t *row_start, c
 static int embed_impl(const int32_t *tokens, const int32_t *species, const float *tok_table,
                       const float *species_table, float *x, uint8_t *pad_flags, int32_t *bad_index, int B, int T,
                       int E, int vocab, int n_species, int pad_idx, void *xb, float *ln_rows, float eps,
-                      void *stream) {
-    TC_REQUIRE(tokens && species && tok_table && species_table && x, "tc_embed_fwd: null operand");
+                      void *stream, void *x_lo = nullptr) {
+    TC_REQUIRE(tokens && species && tok_table && species_table && (x || (xb && x_lo)), "tc_embed_fwd: null operand");
+    TC_REQUIRE(tc_aligned16(x_lo) && (!x_lo || xb), "tc_embed_fwd_ln: the remainder plane comes with the bf16 plane, 16-byte aligned");
     TC_REQUIRE(B > 0 && T > 0 && E > 0 && E % 4 == 0, "tc_embed_fwd: bad shape B=%d T=%d E=%d", B, T, E);
     TC_REQUIRE(tc_aligned16(tok_table) && tc_aligned16(species_table) && tc_aligned16(x),
                "tc_embed_fwd: tables and output must be 16-byte aligned");
@@ -610,7 +640,7 @@ static int embed_impl(const int32_t *tokens, const int32_t *species, const float
     TcProfScope prof(TC_PROF_EMBED, s, (double)M * (4.0 + (xb ? 6.0 : 4.0) * E));
     TC_LAUNCH(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, tokens, species,
                        tok_table, species_table, x, pad_flags, bad_index, (int)M, T, E, vocab,
-                       n_species, pad_idx, static_cast<uint16_t *>(xb), ln_rows, eps);
+                       n_species, pad_idx, static_cast<uint16_t *>(xb), ln_rows, eps, static_cast<uint16_t *>(x_lo));
     TC_CHECK_LAUNCH("tc_embed_fwd");
     return TC_OK;
 }
@@ -625,11 +655,11 @@ extern "C" int tc_embed_fwd(const int32_t *tokens, const int32_t *species, const
 
 extern "C" int tc_embed_fwd_ln(const int32_t *tokens, const int32_t *species, const float *tok_table,
                                const float *species_table, float *x, uint8_t *pad_flags, int32_t *bad_index, int B,
-                               int T, int E, int vocab, int n_species, int pad_idx, void *xb, float *ln_rows,
-                               float eps, void *stream) {
+                               int T, int E, int vocab, int n_species, int pad_idx, void *xb, void *x_lo,
+                               float *ln_rows, float eps, void *stream) {
     TC_REQUIRE(xb && ln_rows, "tc_embed_fwd_ln: null operand");
     return embed_impl(tokens, species, tok_table, species_table, x, pad_flags, bad_index, B, T, E, vocab, n_species,
-                      pad_idx, xb, ln_rows, eps, stream);
+                      pad_idx, xb, ln_rows, eps, stream, x_lo);
 }
 
 extern "C" int tc_ln_rows_finalize(unsigned long long *row_acc, float *ln_rows, int M, int E, float eps, void *stream) {
@@ -654,12 +684,11 @@ extern "C" int tc_ln_fold_weights(const float *W, const float *gamma, const floa
     return TC_OK;
 }
 
-extern "C" int tc_layernorm_fwd(const float *x, const float *gamma, const float *beta,
-                                float *out_f32, void *out_bf16, int M, int E, float eps,
-                                void *stream) {
-    TC_REQUIRE(x && gamma && beta && (out_f32 || out_bf16), "tc_layernorm_fwd: null operand");
+static int layernorm_impl(const float *x, const uint16_t *x_hi, const uint16_t *x_lo, const float *gamma,
+                          const float *beta, float *out_f32, void *out_bf16, int M, int E, float eps, void *stream) {
+    TC_REQUIRE((x || (x_hi && x_lo)) && gamma && beta && (out_f32 || out_bf16), "tc_layernorm_fwd: null operand");
     TC_REQUIRE(M > 0 && E > 0 && E % 4 == 0 && E <= 2048, "tc_layernorm_fwd: bad shape M=%d E=%d", M, E);
-    TC_REQUIRE(tc_aligned16(x) && tc_aligned16(gamma) && tc_aligned16(beta) &&
+    TC_REQUIRE(tc_aligned16(x) && tc_aligned16(x_hi) && tc_aligned16(x_lo) && tc_aligned16(gamma) && tc_aligned16(beta) &&
                    tc_aligned16(out_f32) && (((uintptr_t)out_bf16) & 7u) == 0,
                "tc_layernorm_fwd: misaligned operand");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -668,7 +697,7 @@ extern "C" int tc_layernorm_fwd(const float *x, const float *gamma, const float 
     const dim3 grid((M + 3) / 4), block(256);
     uint16_t *ob = static_cast<uint16_t *>(out_bf16);
     const int nch = (E + 255) / 256;
-#define TC_LN(N) TC_LAUNCH(layernorm_kernel<N>, grid, block, 0, s, x, gamma, beta, out_f32, ob, M, E, eps)
+#define TC_LN(N) TC_LAUNCH(layernorm_kernel<N>, grid, block, 0, s, x, gamma, beta, out_f32, ob, M, E, eps, x_hi, x_lo)
     switch (nch) {
         case 1: TC_LN(1); break;
         case 2: TC_LN(2); break;
@@ -678,6 +707,32 @@ extern "C" int tc_layernorm_fwd(const float *x, const float *gamma, const float 
     }
 #undef TC_LN
     TC_CHECK_LAUNCH("tc_layernorm_fwd");
+    return TC_OK;
+}
+
+extern "C" int tc_layernorm_fwd(const float *x, const float *gamma, const float *beta,
+                                float *out_f32, void *out_bf16, int M, int E, float eps,
+                                void *stream) {
+    TC_REQUIRE(x, "tc_layernorm_fwd: null operand");
+    return layernorm_impl(x, nullptr, nullptr, gamma, beta, out_f32, out_bf16, M, E, eps, stream);
+}
+
+extern "C" int tc_layernorm_fwd_split(const void *x_hi, const void *x_lo, const float *gamma, const float *beta,
+                                      float *out_f32, void *out_bf16, int M, int E, float eps, void *stream) {
+    TC_REQUIRE(x_hi && x_lo, "tc_layernorm_fwd_split: null operand");
+    return layernorm_impl(nullptr, static_cast<const uint16_t *>(x_hi), static_cast<const uint16_t *>(x_lo), gamma, beta,
+                          out_f32, out_bf16, M, E, eps, stream);
+}
+
+extern "C" int tc_split_to_f32(const void *x_hi, const void *x_lo, float *out, long n, void *stream) {
+    TC_REQUIRE(x_hi && x_lo && out && n > 0 && n % 4 == 0, "tc_split_to_f32: bad operand");
+    TC_REQUIRE(tc_aligned16(x_hi) && tc_aligned16(x_lo) && tc_aligned16(out), "tc_split_to_f32: misaligned operand");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long n4 = n / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536);
+    TC_LAUNCH(split_to_f32_kernel, dim3(grid), dim3(256), 0, s, static_cast<const uint16_t *>(x_hi),
+              static_cast<const uint16_t *>(x_lo), out, n4);
+    TC_CHECK_LAUNCH("tc_split_to_f32");
     return TC_OK;
 }
 
