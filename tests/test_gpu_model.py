@@ -281,11 +281,12 @@ def test_folded_layernorm_forward_against_separate_kernels_and_oracle(full_sd, f
         lib.tc_prof_reset()
         lib.tc_prof_enable(1)
         with torch.no_grad():
-            out = full_bf16(t_d, s_d)
+            out = full_bf16(t_d, s_d, repr_layers=[0, 5, 12])
         torch.cuda.synchronize()
         lib.tc_prof_enable(0)
         runs[fold] = (out["logits"].float().cpu().numpy(), _lib.prof_collect(_lib.PROF_LN_ROWS)[0],
-                      _lib.prof_collect(_lib.PROF_LAYERNORM)[0])
+                      _lib.prof_collect(_lib.PROF_LAYERNORM)[0],
+                      {k: v[[0, 3, 41]].float().cpu().numpy() for k, v in out["representations"].items()})
     full_bf16.fold_layernorm = True
     assert runs[True][1] == 23 and runs[True][2] == 1
     assert runs[False][1] == 0 and runs[False][2] == 25
@@ -299,6 +300,17 @@ def test_folded_layernorm_forward_against_separate_kernels_and_oracle(full_sd, f
         err[fold] = float(np.sqrt(np.mean((got - ref)[keep] ** 2)))
     print(f"\nrms logit error against the oracle: folded {err[True]:.4e}, separate kernels {err[False]:.4e}")
     assert err[True] <= 1.25 * err[False] + 1e-4
+    # representations: the folded forward has no f32 residual stream (bf16 hi + lo planes); layer 0 is the
+    # embedding sum (exact to 16 bits of mantissa), the inner layer and the final states stay within
+    # the bf16 path's tolerance of the oracle's
+    ref_rep = O.forward(full_sd, O.FULL, torch.from_numpy(tok[rows]), torch.from_numpy(sp[rows]), repr_layers=(0, 5, 12))["representations"]
+    for fold in (True, False):
+        rep = runs[fold][3]
+        assert set(rep) == {0, 5, 12}
+        np.testing.assert_allclose(rep[0][keep], ref_rep[0].numpy()[keep], rtol=2.0 ** -15, atol=1e-6)
+        for layer in (5, 12):
+            d = np.abs(rep[layer] - ref_rep[layer].numpy())[keep]
+            assert float(d.max()) < 0.15, (fold, layer, float(d.max()))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

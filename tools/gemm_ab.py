@@ -28,6 +28,9 @@ def load(path):
     if hasattr(lib, "tc_gemm_residual_split"):
         res, args = _lib._SIGNATURES["tc_gemm_residual_split"]
         lib.tc_gemm_residual_split.restype, lib.tc_gemm_residual_split.argtypes = res, args
+    if hasattr(lib, "tc_gemm_ln"):
+        res, args = _lib._SIGNATURES["tc_gemm_ln"]
+        lib.tc_gemm_ln.restype, lib.tc_gemm_ln.argtypes = res, args
     if hasattr(lib, "tc_gemm_residual_ln"):
         res, args = _lib._SIGNATURES["tc_gemm_residual_ln"]
         lib.tc_gemm_residual_ln.restype, lib.tc_gemm_residual_ln.argtypes = res, args
@@ -66,6 +69,10 @@ def main():
               # the new build keeps the residual stream as two bf16 planes, updated in place
               "out_split": (x, E, E, E, _lib.EPI_BIAS_RESIDUAL, E, True),
               "fc2_split": (mid, F + 64, E, F, _lib.EPI_BIAS_RESIDUAL, E, True)}
+    # the new build runs these with a LayerNorm folded in (row pairs + column sums in the epilogue)
+    shapes["qkv_fold"] = shapes["qkv"]
+    shapes["fc1_fold"] = shapes["fc1"]
+    ln_rows = torch.rand(M, 2, device=dev, generator=g) + 0.5
     plane_hi = torch.randn(M, E, device=dev, generator=g).bfloat16()
     plane_lo = (torch.randn(M, E, device=dev, generator=g) * 1e-3).bfloat16()
     copy16 = torch.empty(M, E, device=dev, dtype=torch.bfloat16)
@@ -80,6 +87,11 @@ def main():
             if name.endswith("_ln") and k == "new":
                 rc = libs[k].tc_gemm_residual_ln(1, A.data_ptr(), lda, w.data_ptr(), b.data_ptr(), res.data_ptr(),
                                                  outs[k].data_ptr(), copy16.data_ptr(), row_acc.data_ptr(), ldo, M, N, K, strm)
+                assert rc == 0, libs[k].tc_last_error()
+                return
+            if name.endswith("_fold") and k == "new":
+                rc = libs[k].tc_gemm_ln(1, epi, A.data_ptr(), lda, w.data_ptr(), b.data_ptr(), b.data_ptr(), ln_rows.data_ptr(),
+                                        outs[k].data_ptr(), ldo, M, N, K, 0.125, cos.data_ptr(), sin.data_ptr(), T, 64, strm)
                 assert rc == 0, libs[k].tc_last_error()
                 return
             if name.endswith("_split") and k == "new":

@@ -26,8 +26,11 @@ def short(name):
         e = re.search(r"Li(\d)E", name) or re.search(r",\s*(\d)\s*>", name)
         # the profiler's demangler garbles the <__bf16, 1> instantiation into "<bool _Accum, int, E>"
         # the profiler's demangler also garbles the three-argument forms: "<bool _Accum, int, ELb, E>" is
-        # <__bf16, 3, true>, "<bool _Accum, int, E, true>" is <__bf16, 1, true>
-        if "_Accum" in name and "ELb, E" in name:
+        # <__bf16, 3, true>, "<bool _Accum, int, E, true>" is <__bf16, 1, true>, "<bool _Accum, int, EL, bool, E>"
+        # is <__bf16, 2, true>
+        if "_Accum" in name and "EL, bool, E" in name:
+            base += "<epi=2>+split"         # <__bf16, 2, true>: residual product on the bf16 hi/lo planes
+        elif "_Accum" in name and "ELb, E" in name:
             base += "<epi=3>+ln"
         else:
             base += "<epi=%s>" % (e.group(1) if e else ("1" if "_Accum" in name else "?"))
