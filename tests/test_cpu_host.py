@@ -211,3 +211,67 @@ def test_bench_launcher_starts_one_rank_per_gpu():
                        env=env, capture_output=True, text=True, timeout=300)
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and lines[0]["rank"] == 3 and lines[0]["world"] == 4
+
+
+def test_array_tokenisation_equals_the_string_path():
+    """template_token_ids / cds_token_ids (byte lookup tables, used by the batched drivers) against the
+    string path they replace: AA_tokenize -> CodonSequence_infer / WithUtr_CodonSequence_infer ->
+    Alphabet.encode (infer.py:113-129, sequence.py:60-79), including truncation, T -> U, blanks and the
+    KeyError on foreign letters."""
+    import numpy as np
+    from transcodon_amd import infer_utr as I
+    from transcodon_amd.sequence import CodonSequence
+    rng = np.random.default_rng(5)
+    aas = "FLIMVPTAYHQNKDECWRSG"
+    for trial in range(40):
+        prot = "".join(rng.choice(list(aas), int(rng.integers(1, 60))))
+        utr = None if trial % 2 else "".join(rng.choice(list("ACGTU "), int(rng.integers(0, 30))))
+        max_aa = [None, 2048, 7][trial % 3]
+        aa = prot + "_"
+        tmpl = I.AA_tokenize(aa)
+        want_aa = aa
+        if max_aa is not None and len(tmpl) > 3 * max_aa:
+            want_aa, tmpl = aa[:max_aa], tmpl[:3 * max_aa]
+        seq = I.CodonSequence_infer(tmpl) if utr is None else I.WithUtr_CodonSequence_infer(utr, tmpl)
+        want = I._ALPHABET.encode(seq.seq)
+        ids, start, got_aa = I.template_token_ids(aa, utr, max_aa)
+        assert ids.dtype == np.int32 and ids.tolist() == want
+        assert got_aa == want_aa
+        assert start == 1 + (0 if utr is None else len(utr.replace(" ", "")) + 1)
+        cds = "".join(rng.choice(list("ACGTU"), 3 * int(rng.integers(1, 40))))
+        assert I.cds_token_ids(cds).tolist() == I._ALPHABET.encode(CodonSequence("", cds).seq)
+    for bad in ("MKX_", "MB_", "Mk_"):
+        with pytest.raises(KeyError):
+            I.AA_tokenize(bad)
+        with pytest.raises(KeyError):
+            I.template_token_ids(bad)
+    with pytest.raises(KeyError):
+        I.template_token_ids("MK_", "ACGN")
+    with pytest.raises(KeyError):
+        I.cds_token_ids("ACGN")
+
+
+def test_batched_back_translation_check_equals_the_string_one():
+    import numpy as np
+    from transcodon_amd import infer_utr as I
+    from transcodon_amd.sequence import CODON_TO_AA
+    rng = np.random.default_rng(8)
+    by_aa = {}
+    for codon, aa in CODON_TO_AA.items():
+        by_aa.setdefault("_" if aa == "#" else aa, []).append(codon)
+    prots = ["".join(rng.choice(list("FLIMVPTAYHQNKDECWRSG"), int(rng.integers(2, 30)))) + "_" for _ in range(12)]
+    rnas = ["".join(by_aa[a][int(rng.integers(len(by_aa[a])))] for a in p) for p in prots]
+    offs = np.concatenate([[0], np.cumsum([len(p) for p in prots])])
+    letters = np.frombuffer("".join(prots).encode(), np.uint8)
+    flat = np.frombuffer("".join(rnas).encode(), np.uint8)
+    assert all(I.back_translation_ok(r, p) for r, p in zip(rnas, prots))
+    assert I.back_translation_mismatch(flat, letters, offs) == -1
+    # a wrong last codon is not looked at by either form; a wrong inner codon is found by both
+    broken = list(rnas)
+    broken[4] = broken[4][:-3] + "AUG"
+    assert I.back_translation_ok(broken[4], prots[4])
+    assert I.back_translation_mismatch(np.frombuffer("".join(broken).encode(), np.uint8), letters, offs) == -1
+    wrong = "UGG" if prots[7][1] != "W" else "AUG"
+    broken[7] = broken[7][:3] + wrong + broken[7][6:]
+    assert not I.back_translation_ok(broken[7], prots[7])
+    assert I.back_translation_mismatch(np.frombuffer("".join(broken).encode(), np.uint8), letters, offs) == 7

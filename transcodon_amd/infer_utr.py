@@ -42,6 +42,89 @@ def AA_tokenize(seq: str) -> str:
     return "".join(parts)
 
 
+# ---- the same tokenisation as arrays ---------------------------------------------------------
+# AA_tokenize -> CodonSequence_infer / WithUtr_CodonSequence_infer -> Alphabet.encode walks Python
+# strings symbol by symbol (0.7 M tokens/s on one core, a seventh of what one GPU consumes); the
+# batched drivers build the same token ids from byte lookup tables instead.
+import numpy as _np
+
+_TOK = _ALPHABET.tok_to_idx
+_BASE_LUT = _np.full(256, -1, _np.int16)
+for _ch in "AUCG":
+    _BASE_LUT[ord(_ch)] = _TOK[_ch]
+_BASE_LUT[ord("T")] = _TOK["U"]                       # T is read as U (sequence.py:60-62,78-79)
+_TMPL_LUT = _BASE_LUT.copy()
+_TMPL_LUT[ord("*")] = _TOK["<mask>"]                  # '*' of a template becomes <mask> (sequence.py:67-68)
+_AA_LUT = _np.full((256, 3), -1, _np.int16)
+for _aa in "FLIMVPTAYHQNKDECWRSG_":
+    _AA_LUT[ord(_aa)] = [_TMPL_LUT[ord(_c)] for _c in AA_tokenize(_aa + "_")[:3]]
+_STOP_IDS = _np.array([_TMPL_LUT[ord(_c)] for _c in "U**"], _np.int16)
+
+
+def _lut_ids(text: str, lut) -> "_np.ndarray":
+    try:
+        raw = _np.frombuffer(text.replace(" ", "").encode("ascii"), _np.uint8)
+    except UnicodeEncodeError as e:
+        raise KeyError(text[e.start]) from None
+    ids = lut[raw]
+    if ids.size and int(ids.min()) < 0:
+        raise KeyError(chr(int(raw[int(_np.argmax(ids < 0))])))      # the first foreign symbol, as Alphabet.encode
+    return ids
+
+
+def template_token_ids(aa_seq: str, utr: Optional[str] = None, max_aa: Optional[int] = None):
+    """Token ids of `<cls> [utr <sep>] template <eos>` for a protein whose last character stands for
+    the stop codon: what Alphabet.encode(CodonSequence_infer(AA_tokenize(aa_seq)).seq) returns (or the
+    WithUtr form), as an int32 array.  Returns (ids, first CDS row, the amino acids actually covered):
+    like infer.py:262-269, a template longer than 3 * max_aa bases is cut there."""
+    raw = _np.frombuffer(aa_seq.encode("ascii", "replace"), _np.uint8)
+    body = _AA_LUT[raw[:-1]]
+    if body.size and int(body.min()) < 0:
+        raise KeyError(aa_seq[int(_np.argmax(body.min(axis=1) < 0))])
+    tmpl = _np.concatenate([body.reshape(-1), _STOP_IDS])
+    if max_aa is not None and tmpl.size > 3 * max_aa:
+        aa_seq, tmpl = aa_seq[:max_aa], tmpl[:3 * max_aa]
+    parts = [_np.array([_TOK["<cls>"]], _np.int16)]
+    start = 1
+    if utr is not None:
+        u = _lut_ids(utr, _TMPL_LUT)
+        parts += [u, _np.array([_TOK["<sep>"]], _np.int16)]
+        start += u.size + 1
+    parts += [tmpl, _np.array([_TOK["<eos>"]], _np.int16)]
+    return _np.concatenate(parts).astype(_np.int32), start, aa_seq
+
+
+def cds_token_ids(cds: str) -> "_np.ndarray":
+    """Token ids of `<cls> cds <eos>` (T read as U): Alphabet.encode(CodonSequence("", cds).seq)."""
+    return _np.concatenate([[_TOK["<cls>"]], _lut_ids(cds, _BASE_LUT), [_TOK["<eos>"]]]).astype(_np.int32)
+
+
+# codon (16 a + 4 b + c over A, U, C, G = 0..3) -> amino-acid letter as a byte, '#' for the stop codons
+_B4 = _np.full(256, -1, _np.int16)
+for _i, _ch in enumerate("AUCG"):
+    _B4[ord(_ch)] = _i
+_CODON_AA = _np.zeros(64, _np.uint8)
+for _a in range(4):
+    for _b in range(4):
+        for _c in range(4):
+            _CODON_AA[16 * _a + 4 * _b + _c] = ord(CODON_TO_AA["AUCG"[_a] + "AUCG"[_b] + "AUCG"[_c]])
+
+
+def back_translation_mismatch(bases: "_np.ndarray", aa_letters: "_np.ndarray", offsets: Sequence[int]) -> int:
+    """The check of back_translation_ok for a whole decoded batch at once: bases uint8 [3 * n_aa] (ASCII
+    A/U/C/G), aa_letters uint8 [n_aa] (the proteins with their stop markers, concatenated), offsets
+    [n_seq + 1] into the amino acids.  Every codon but each sequence's last must translate to its amino
+    acid (infer.py:76-88 compares res[:-1]).  Returns the index of the first sequence that does not, or -1."""
+    b = _B4[bases].astype(_np.int64).reshape(-1, 3)
+    aa = _CODON_AA[16 * b[:, 0] + 4 * b[:, 1] + b[:, 2]]
+    bad = aa != aa_letters
+    off = _np.asarray(offsets, _np.int64)
+    bad[off[1:] - 1] = False                                  # the last codon of a sequence is not compared
+    if not bad.any():
+        return -1
+    return int(_np.searchsorted(off, int(_np.argmax(bad)), side="right") - 1)
+
+
 def back_translation_ok(rna: str, aa_seq: str) -> bool:
     res = "".join(CODON_TO_AA[rna[i:i + 3]] for i in range(0, len(rna), 3))
     return res[:-1] == aa_seq[:len(res)][:-1]
@@ -131,7 +214,7 @@ def extract_embeddings(model, cds_seqs: Sequence[str], organisms: Sequence[Union
     from .sequence import CodonSequence
     dev = _model_device(model)
     L = model.num_layers
-    enc = [_ALPHABET.encode(CodonSequence("", s).seq)[:max_positions] for s in cds_seqs]
+    enc = [cds_token_ids(s)[:max_positions] for s in cds_seqs]
     species = [_species_id(o) for o in organisms]
     out = [None] * len(enc)
     with _HostCheckedIds(model, species):
@@ -176,7 +259,7 @@ def _extract(model, enc, species, out, dev, L, max_batch_tokens, pooled, packed)
             pos += 1
         tok = torch.full((len(chunk), width), _ALPHABET.padding_idx, dtype=torch.int32)
         for r, k in enumerate(chunk):
-            tok[r, :len(enc[k])] = torch.tensor(enc[k], dtype=torch.int32)
+            tok[r, :len(enc[k])] = torch.from_numpy(_np.asarray(enc[k], _np.int32))
         with torch.no_grad():
             rep = model(tok.to(dev), torch.tensor([species[k] for k in chunk], dtype=torch.int32, device=dev),
                         repr_layers=[L])["representations"][L]
@@ -206,14 +289,7 @@ def optimize_codons(model, proteins: Sequence[str], organisms: Sequence[Union[in
     dev = _model_device(model)
     items = []
     for i, prot in enumerate(proteins):
-        aa = prot + "_"
-        tmpl = AA_tokenize(aa)
-        if len(tmpl) > 3 * max_aa:
-            aa, tmpl = aa[:max_aa], tmpl[:3 * max_aa]
-        utr = None if utrs is None else utrs[i]
-        seq = CodonSequence_infer(tmpl) if utr is None else WithUtr_CodonSequence_infer(utr, tmpl)
-        ids = _ALPHABET.encode(seq.seq)
-        start = 1 + (0 if utr is None else len(utr.replace(" ", "")) + 1)
+        ids, start, aa = template_token_ids(prot + "_", None if utrs is None else utrs[i], max_aa)
         items.append((i, ids, start, aa, _species_id(organisms[i])))
     with _HostCheckedIds(model, [it[4] for it in items]):
         return _optimize(model, items, dev, max_batch_tokens, packed)
@@ -252,7 +328,7 @@ def _optimize(model, items, dev, max_batch_tokens, packed):
         else:
             tok = torch.full((B, width), _ALPHABET.padding_idx, dtype=torch.int32)
             for r, (_, ids, _, _, _) in enumerate(chunk):
-                tok[r, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+                tok[r, :len(ids)] = torch.from_numpy(np.asarray(ids, np.int32))
             species = torch.tensor([c[4] for c in chunk], dtype=torch.int32)
             row0 = [r * width + c[2] for r, c in enumerate(chunk)]
             with torch.no_grad():
@@ -262,10 +338,11 @@ def _optimize(model, items, dev, max_batch_tokens, packed):
             torch.frombuffer(bytearray(aa_all), dtype=torch.uint8).to(dev),
             torch.tensor(offs, dtype=torch.int32, device=dev),
             torch.tensor(row0, dtype=torch.int32, device=dev))
-        flat_s = bytes(bases.cpu().numpy()).decode("ascii")
+        host = bases.cpu().numpy()
+        wrong = back_translation_mismatch(host, np.frombuffer("".join(c[3] for c in chunk).encode("ascii"), np.uint8), offs)
+        if wrong >= 0:
+            raise RuntimeError(f"prediction for sequence {chunk[wrong][0]} does not translate back to its protein")
+        flat_s = host.tobytes().decode("ascii")
         for r, c in enumerate(chunk):
-            rna = flat_s[3 * offs[r]:3 * offs[r + 1]]
-            if not back_translation_ok(rna, c[3]):
-                raise RuntimeError(f"prediction for sequence {c[0]} does not translate back to its protein")
-            out[c[0]] = rna
+            out[c[0]] = flat_s[3 * offs[r]:3 * offs[r + 1]]
     return out
