@@ -139,6 +139,15 @@ int tc_key_mask_words(const uint8_t *pad_flags, uint64_t *words, int B, int T, v
  */
 int tc_attn_fwd(int dtype, const void *qkv, int ldq, const uint64_t *key_words, void *out, int B,
                 int T, int H, int D, void *stream);
+/*
+ * The same product for q rows scaled by log2(e) / sqrt(D) instead of 1 / sqrt(D) (the q/k/v product's
+ * q_scale argument; multihead_attention.py:350 scales by head_dim ** -0.5).  The scores then come out of
+ * the matrix unit in base-2 units, the running softmax offset enters as the accumulator's start value and
+ * exp2 applies to the accumulators directly: one multiply-add per score less.  bf16 only; the result is
+ * the same softmax (the factor is a change of the exponential's base).  tc_encoder_forward uses it.
+ */
+int tc_attn_fwd_q2(int dtype, const void *qkv, int ldq, const uint64_t *key_words, void *out, int B, int T, int H,
+                   int D, void *stream);
 
 /*
  * Pre-softmax attention scores for need_head_weights=True callers:
@@ -473,6 +482,9 @@ int tc_gemm_qkv_packed(int dtype, const void *A, int lda, const void *W, const f
 int tc_attn_packed_block_rows(int dtype);
 int tc_attn_fwd_packed(int dtype, const void *qkv, int ldq, const int32_t *blocks, int n_blocks, int max_len,
                        void *out, int H, int D, double flops, void *stream);
+/* tc_attn_fwd_packed for q rows scaled by log2(e) / sqrt(D) (see tc_attn_fwd_q2); bf16 only */
+int tc_attn_fwd_packed_q2(int dtype, const void *qkv, int ldq, const int32_t *blocks, int n_blocks, int max_len,
+                          void *out, int H, int D, double flops, void *stream);
 int tc_mean_pool_packed(const float *rep, const int32_t *row_start, const int32_t *len, float *pooled, int n_seq,
                         int total_rows, int E, void *stream);
 int tc_encoder_forward_packed(const tc_encoder_desc *desc, const int32_t *tokens, const int32_t *species_row,

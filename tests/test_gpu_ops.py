@@ -286,44 +286,72 @@ def _attn_ref(qkv, B, T, H, pad):
     return (p @ v).permute(0, 2, 1, 3).reshape(B * T, E).float(), s.float()
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+LOG2E = 1.4426950408889634
+
+
+def _q2_pair(qkv, E):
+    """bf16 input whose q columns carry the extra factor log2(e) (what tc_attn_fwd_q2 takes), and the f32
+    input with exactly those rounded values divided by log2(e) again, for the float64 reference."""
+    x = qkv.clone()
+    x[:, :E] *= LOG2E
+    x = _bf(x)
+    ref_in = x.double()
+    ref_in[:, :E] /= LOG2E
+    return x, ref_in
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, "bf16_q2"])
 @pytest.mark.parametrize("B,T,H,lens", [(2, 131, 2, None), (3, 256, 3, [256, 130, 1]), (2, 70, 1, [70, 64]),
-                                        (1, 515, 2, None), (2, 300, 2, [300, 257])])
+                                        (1, 515, 2, None), (2, 300, 2, [300, 257]), (2, 200, 1, [0, 200])])
 def test_attention_forward(dtype, B, T, H, lens):
     E = H * 64
+    q2 = dtype == "bf16_q2"
+    if q2:
+        dtype = torch.bfloat16
     qkv = _rand(B * T, 3 * E, seed=21)
     qkv[:, :E] *= 0.25
-    if dtype == torch.bfloat16:
+    ref_in = None
+    if q2:
+        qkv, ref_in = _q2_pair(qkv, E)
+    elif dtype == torch.bfloat16:
         qkv = _bf(qkv)
     pad = None
     if lens is not None:
         pad = torch.zeros(B, T, dtype=torch.uint8)
         for b, L in enumerate(lens):
             pad[b, L:] = 1
-    ref, sref = _attn_ref(qkv, B, T, H, pad)
+    ref, sref = _attn_ref(qkv if ref_in is None else ref_in, B, T, H, pad)
     words = ops.key_mask_words(pad.to(DEV).view(-1), B, T) if pad is not None else None
-    out = ops.attention(qkv.to(DEV, dtype), B, T, H, words).float().cpu()
+    out = ops.attention(qkv.to(DEV, dtype), B, T, H, words, q2=q2).float().cpu()
     keep = torch.ones(B * T, dtype=torch.bool) if pad is None else (pad.view(-1) == 0)
     tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(out[keep].numpy(), ref[keep].numpy(), **tol)
+    if q2:
+        with pytest.raises(_lib.HipLibraryError):       # the base-2 entry is bf16 only
+            ops.attention(qkv.to(DEV, torch.float32), B, T, H, words, q2=True)
+        return
     sc = ops.attention_scores(qkv.to(DEV, dtype), B, T, H, pad.to(DEV).view(-1) if pad is not None else None).cpu()
     finite = torch.isfinite(sref)
     assert torch.equal(torch.isfinite(sc), finite)
     np.testing.assert_allclose(sc[finite].numpy(), sref[finite].numpy(), rtol=1e-4, atol=1e-4)
 
 
-def test_attention_online_softmax_rescale():
+@pytest.mark.parametrize("q2", [False, True])
+def test_attention_online_softmax_rescale(q2):
     """A key far above the others late in the sequence forces the running-max rescale."""
     B, T, H = 1, 192, 1
     qkv = _bf(_rand(T, 192, seed=22))
     qkv[:, :64] *= 0.1
     qkv[150, 64:128] = _bf(qkv[5, :64] * 40.0)      # key 150 aligned with query 5
-    ref, _ = _attn_ref(qkv, B, T, H, None)
-    out = ops.attention(qkv.to(DEV, torch.bfloat16), B, T, H).float().cpu()
+    ref_in = qkv
+    if q2:
+        qkv, ref_in = _q2_pair(qkv, 64)
+    ref, _ = _attn_ref(ref_in, B, T, H, None)
+    out = ops.attention(qkv.to(DEV, torch.bfloat16), B, T, H, q2=q2).float().cpu()
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, "bf16_q2"])
 def test_attention_lazy_running_maximum_staircase(dtype):
     """The bf16 kernel moves its softmax offset only when a key tile's maximum exceeds it by more
     than 2^8; scores that climb tile after tile (steps below and above that threshold, in both
@@ -339,6 +367,13 @@ def test_attention_lazy_running_maximum_staircase(dtype):
     steps = torch.tensor([0.0, 3.5, 7.0, 4.0, -20.0, 30.0, 33.0, 12.0])
     k[:, 0] = steps.repeat_interleave(64).repeat(B)
     qkv = torch.cat([q, k, v], 1)
+    if dtype == "bf16_q2":
+        # base-2 entry: q carries log2(e); the reference sees exactly the rounded values
+        qkv, ref_in = _q2_pair(qkv, 64)
+        ref, _ = _attn_ref(ref_in, B, T, H, None)
+        out = ops.attention(qkv.to(DEV, torch.bfloat16), B, T, H, q2=True).float().cpu()
+        np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+        return
     if dtype == torch.bfloat16:
         qkv = _bf(qkv)
     ref, _ = _attn_ref(qkv, B, T, H, None)

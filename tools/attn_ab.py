@@ -15,11 +15,13 @@ sys.path.insert(0, ROOT)
 from transcodon_amd import _lib  # noqa: E402
 
 
-def load(path):
+def load(path, q2=False):
+    """-> the library's forward entry: tc_attn_fwd, or tc_attn_fwd_q2 (q pre-multiplied by log2(e))"""
     lib = C.CDLL(path)
     res, args = _lib._SIGNATURES["tc_attn_fwd"]
-    lib.tc_attn_fwd.restype, lib.tc_attn_fwd.argtypes = res, args
-    return lib
+    fn = lib.tc_attn_fwd_q2 if q2 else lib.tc_attn_fwd
+    fn.restype, fn.argtypes = res, args
+    return fn
 
 
 def main():
@@ -29,8 +31,9 @@ def main():
     ap.add_argument("--shapes", default="256x512,128x1024,32x2048")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--q2", action="store_true", help="time the new library's base-2 entry (tc_attn_fwd_q2)")
     a = ap.parse_args()
-    libs = {"base": load(a.base), "new": load(a.new)}
+    libs = {"base": load(a.base), "new": load(a.new, a.q2)}
     H, E = 12, 768
     strm = torch.cuda.current_stream().cuda_stream
     for shp in a.shapes.split(","):
@@ -38,11 +41,14 @@ def main():
         g = torch.Generator(device="cuda").manual_seed(1)
         qkv = torch.randn(B * T, 3 * E, device="cuda", generator=g)
         qkv[:, :E] *= 0.125
-        qkv = qkv.bfloat16()
+        qkv2 = qkv.clone()
+        qkv2[:, :E] *= 1.4426950408889634
+        qkv, qkv2 = qkv.bfloat16(), qkv2.bfloat16()
         outs = {k: torch.empty(B * T, E, device="cuda", dtype=torch.bfloat16) for k in libs}
 
         def run(k):
-            assert libs[k].tc_attn_fwd(1, qkv.data_ptr(), 3 * E, None, outs[k].data_ptr(), B, T, H, 64, strm) == 0
+            src = qkv2 if (k == "new" and a.q2) else qkv
+            assert libs[k](1, src.data_ptr(), 3 * E, None, outs[k].data_ptr(), B, T, H, 64, strm) == 0
 
         for k in libs:
             run(k)

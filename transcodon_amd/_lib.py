@@ -81,6 +81,7 @@ _SIGNATURES = {
                           C.c_int, C.c_int, C.c_float, vp, vp, C.c_int, C.c_int, vp]),
     "tc_key_mask_words": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "tc_attn_fwd": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "tc_attn_fwd_q2": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "tc_attn_scores": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "tc_head_logits_fwd": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp,
                                      C.c_int, C.c_int, C.c_int, C.c_float, vp]),
@@ -114,6 +115,7 @@ _SIGNATURES = {
                                      vp, vp, vp, C.c_int, C.c_int, vp]),
     "tc_attn_packed_block_rows": (C.c_int, [C.c_int]),
     "tc_attn_fwd_packed": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_double, vp]),
+    "tc_attn_fwd_packed_q2": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_double, vp]),
     "tc_mean_pool_packed": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "tc_encoder_forward_packed": (C.c_int, [C.POINTER(EncoderDesc), vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp,
                                             vp, C.c_size_t, vp]),

@@ -71,7 +71,11 @@ __device__ __forceinline__ uint64_t key_word(const AttnParams &p, int b, int kt,
     return rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
 }
 
-__global__ __launch_bounds__(64 * kWaves) void attn_bf16_kernel(const AttnParams p) {
+// Q2: the caller's q rows are multiplied by log2(e) / sqrt(head_dim) instead of 1 / sqrt(head_dim), so the
+// MFMA results are the scores in base-2 units and the running offset enters as the C operand of the first
+// MFMA of each chain: exp2 applies to the accumulators as they are (no multiply-add per score).
+template <bool Q2>
+__global__ __launch_bounds__(64 * kWaves, 4) void attn_bf16_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -158,14 +162,11 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bf16_kernel(const AttnParams
     };
 
     // ---- LDS read offsets ----
-    // K rows: lane reads row kb*32 + ql, chunk 2 ks + h2
-    int k_off[2][4];
+    // K rows: lane reads row kb*32 + ql, chunk 2 ks + h2; rows 32 apart share the swizzle, so the second
+    // key block is the first one's address + 4096 (an immediate of the read)
+    int k_off[4];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int r = kb * 32 + ql;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) k_off[kb][ks] = r * 128 + (((2 * ks + h2) ^ swz_k(r)) << 4);
-    }
+    for (int ks = 0; ks < 4; ++ks) k_off[ks] = ql * 128 + (((2 * ks + h2) ^ swz_k(ql)) << 4);
     // V transposed reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a
     // 4-key x 16-column block and receives column (lane & 15) of the 4 keys.
     const int tq = (lane & 15) >> 2, tp = lane & 3, thalf = (lane >> 4) & 1;
@@ -180,6 +181,8 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bf16_kernel(const AttnParams
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    // Q2: minus the running offset in all 16 registers of a score block's C operand (0 until a valid key is seen)
+    f32x16 negm16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // LDS byte address of this lane's V reads for d block db, key rows 4 h2 + tq of a stage: the
     // key-block / k-step / upper-half terms are immediates of the read instruction
     const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char *)smem;
@@ -218,21 +221,21 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bf16_kernel(const AttnParams
         if (!q_live) continue;                     // a wave without queries only stages and synchronises
 
         // S^T[key][query]
-        // the first MFMA of each chain takes the constant 0 as its C operand: no accumulator clearing
+        // the first MFMA of each chain takes a constant as its C operand: 0 (no accumulator clearing), or
+        // minus the running offset (Q2)
         f32x16 acc_s[2];
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(sb + k_off[kb][ks]);
-                acc_s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : acc_s[kb], 0, 0, 0);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(sb + k_off[ks] + kb * 4096);
+                acc_s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? (Q2 ? negm16 : zero16) : acc_s[kb], 0, 0, 0);
             }
         }
 
-        // mask + online softmax in base 2.  The running maximum is kept in scaled (log2) units, so
-        // the scale folds into one fma per pair in front of the exponential; the padded-key select
-        // runs only for tiles that contain a padded key (wave-uniform branch).
+        // mask + online softmax in base 2; the padded-key select runs only for tiles that contain a
+        // padded key (wave-uniform branch).
         const uint64_t word = tile_word(kt);
         if (word != ~0ull) {
             const uint64_t wsh = word >> (4 * h2);
@@ -255,38 +258,79 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bf16_kernel(const AttnParams
             tm1 = fmaxf(fmaxf(tm1, acc_s[1][r]), acc_s[1][r + 1]);
         }
         float tmax = fmaxf(tm0, tm1);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * kLog2e;
+        {   // maximum with lane ^ 32 (the other 32 keys of the query) in the vector ALU: no LDS round trip in
+            // the softmax's dependent chain.  The swap leaves x[lane & 31] in a and x[32 + (lane & 31)] in b.
+            float a = tmax, b2 = tmax;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b2));
+            tmax = fmaxf(a, b2);
+        }
         // Lazy running maximum: the offset only moves when a tile's maximum exceeds it by more than
         // kLazy (log2 units), so P stays below 2^kLazy and the rescale of O (32 multiplies per lane)
         // is skipped for nearly every tile.  Exact up to rounding: any per-query offset cancels in the
         // final normalisation, which is done in fp32.
         constexpr float kLazy = 8.0f;
-        const float m_new = (tmax > m_run + kLazy) ? tmax : m_run;     // m_run = -inf: the first valid tile sets it
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-        const f32x2 scale2 = {kLog2e, kLog2e}, neg_m2 = {-m_use, -m_use};
-        f32x2 lsum2 = {0.f, 0.f};
+        if constexpr (Q2) {
+            // the scores already carry minus the offset: tmax is relative to it (absolute before the first valid key)
+            const bool first = m_run == -INFINITY;
+            const bool move = first ? tmax != -INFINITY : tmax > kLazy;
+            if (__builtin_amdgcn_ballot_w64(move) != 0ull) {             // rare: first tile, or a maximum 2^kLazy above the offset
+                const float delta = move ? tmax : 0.f;                   // new offset - old offset
+                const float alpha = (move && first) ? 0.f : __builtin_amdgcn_exp2f(-delta);
+                if (move) m_run = first ? delta : m_run + delta;
+                l_run *= alpha;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 t = f32x2{acc_s[kb][r], acc_s[kb][r + 1]} * scale2 + neg_m2;
-#ifdef TC_ABL_NOEXP
-                const f32x2 e = t;
-#else
-                const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-#endif
-                acc_s[kb][r] = e[0];
-                acc_s[kb][r + 1] = e[1];
-                lsum2 += e;
+                    for (int r = 0; r < 16; ++r) acc_s[kb][r] -= delta;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+                const float nm = m_run == -INFINITY ? 0.f : -m_run;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm16[r] = nm;
             }
-        l_run = l_run * alpha + (lsum2[0] + lsum2[1]);
-        m_run = m_new;
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {      // skip when no lane's maximum moved
+            float lsum0 = 0.f, lsum1 = 0.f;
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+                for (int r = 0; r < 16; r += 2) {
+                    const float e0 = __builtin_amdgcn_exp2f(acc_s[kb][r]), e1 = __builtin_amdgcn_exp2f(acc_s[kb][r + 1]);
+                    acc_s[kb][r] = e0;
+                    acc_s[kb][r + 1] = e1;
+                    lsum0 += e0;
+                    lsum1 += e1;
+                }
+            l_run += lsum0 + lsum1;
+        } else {
+            tmax *= kLog2e;
+            const float m_new = (tmax > m_run + kLazy) ? tmax : m_run;     // m_run = -inf: the first valid tile sets it
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            const f32x2 scale2 = {kLog2e, kLog2e}, neg_m2 = {-m_use, -m_use};
+            f32x2 lsum2 = {0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 t = f32x2{acc_s[kb][r], acc_s[kb][r + 1]} * scale2 + neg_m2;
+#ifdef TC_ABL_NOEXP
+                    const f32x2 e = t;
+#else
+                    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+#endif
+                    acc_s[kb][r] = e[0];
+                    acc_s[kb][r + 1] = e[1];
+                    lsum2 += e;
+                }
+            l_run = l_run * alpha + (lsum2[0] + lsum2[1]);
+            m_run = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {      // skip when no lane's maximum moved
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+            }
         }
 
 #endif
@@ -477,21 +521,45 @@ __global__ __launch_bounds__(256) void scores_kernel(const T *__restrict__ qkv, 
 }  // namespace
 
 static int attn_fwd_impl(int dtype, const void *qkv, int ldq, const uint64_t *key_words, void *out, float *lse,
-                         int B, int T, int H, int D, void *stream);
+                         int B, int T, int H, int D, bool q2, void *stream);
+static int attn_fwd_packed_impl(int dtype, const void *qkv, int ldq, const int32_t *blocks, int n_blocks, int max_len,
+                                void *out, int H, int D, double flops, bool q2, void *stream);
+
+// The bf16 kernel's LDS request, once per variant
+template <bool Q2>
+static int attn_bf16_attr(const char *who) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bf16_kernel<Q2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS_BYTES);
+        if (e != hipSuccess) {
+            tc_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+            return TC_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    return TC_OK;
+}
 
 extern "C" int tc_attn_fwd(int dtype, const void *qkv, int ldq, const uint64_t *key_words,
                            void *out, int B, int T, int H, int D, void *stream) {
-    return attn_fwd_impl(dtype, qkv, ldq, key_words, out, nullptr, B, T, H, D, stream);
+    return attn_fwd_impl(dtype, qkv, ldq, key_words, out, nullptr, B, T, H, D, false, stream);
+}
+
+extern "C" int tc_attn_fwd_q2(int dtype, const void *qkv, int ldq, const uint64_t *key_words, void *out, int B, int T,
+                              int H, int D, void *stream) {
+    TC_REQUIRE(dtype == TC_BF16, "tc_attn_fwd_q2: bf16 only (dtype %d)", dtype);
+    return attn_fwd_impl(dtype, qkv, ldq, key_words, out, nullptr, B, T, H, D, true, stream);
 }
 
 extern "C" int tc_attn_fwd_train(int dtype, const void *qkv, int ldq, const uint64_t *key_words, void *out,
                                  float *lse, int B, int T, int H, int D, void *stream) {
     TC_REQUIRE(lse != nullptr, "tc_attn_fwd_train: lse is required");
-    return attn_fwd_impl(dtype, qkv, ldq, key_words, out, lse, B, T, H, D, stream);
+    return attn_fwd_impl(dtype, qkv, ldq, key_words, out, lse, B, T, H, D, false, stream);
 }
 
 static int attn_fwd_impl(int dtype, const void *qkv, int ldq, const uint64_t *key_words, void *out, float *lse,
-                         int B, int T, int H, int D, void *stream) {
+                         int B, int T, int H, int D, bool q2, void *stream) {
     TC_REQUIRE(dtype == TC_BF16 || dtype == TC_F32, "tc_attn_fwd: bad dtype %d", dtype);
     TC_REQUIRE(qkv && out, "tc_attn_fwd: null operand");
     TC_REQUIRE(D == 64, "tc_attn_fwd: head_dim %d unsupported (only 64)", D);
@@ -512,21 +580,14 @@ static int attn_fwd_impl(int dtype, const void *qkv, int ldq, const uint64_t *ke
     hipStream_t s = static_cast<hipStream_t>(stream);
     TcProfScope prof(TC_PROF_ATTN, s, 4.0 * (double)B * H * (double)T * (double)T * D);
     if (dtype == TC_BF16) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bf16_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS_BYTES);
-            if (e != hipSuccess) {
-                tc_set_error("tc_attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-                return TC_ELAUNCH;
-            }
-            attr_set = true;
-        }
+        const int rc = q2 ? attn_bf16_attr<true>("tc_attn_fwd") : attn_bf16_attr<false>("tc_attn_fwd");
+        if (rc != TC_OK) return rc;
         p.nqb = (T + 32 * kWaves - 1) / (32 * kWaves);
         const long grid = (long)p.nqb * H * B;
         TC_REQUIRE(grid < (1L << 31), "tc_attn_fwd: grid too large");
         TC_REQUIRE(p.nw <= kMaxWords, "tc_attn_fwd: T=%d exceeds the bf16 kernel's %d keys", T, kMaxWords * 64);
-        TC_LAUNCH(attn_bf16_kernel, dim3((unsigned)grid), dim3(64 * kWaves), ATTN_LDS_BYTES, s, p);
+        if (q2) TC_LAUNCH(attn_bf16_kernel<true>, dim3((unsigned)grid), dim3(64 * kWaves), ATTN_LDS_BYTES, s, p);
+        else TC_LAUNCH(attn_bf16_kernel<false>, dim3((unsigned)grid), dim3(64 * kWaves), ATTN_LDS_BYTES, s, p);
     } else {
         p.nqb = (T + 63) / 64;
         const long grid = (long)p.nqb * H * B;
@@ -541,6 +602,17 @@ static int attn_fwd_impl(int dtype, const void *qkv, int ldq, const uint64_t *ke
 // block index, 0) lists the n_blocks (sequence, query block) pairs; query blocks are q_block_rows rows.
 extern "C" int tc_attn_fwd_packed(int dtype, const void *qkv, int ldq, const int32_t *blocks, int n_blocks,
                                   int max_len, void *out, int H, int D, double flops, void *stream) {
+    return attn_fwd_packed_impl(dtype, qkv, ldq, blocks, n_blocks, max_len, out, H, D, flops, false, stream);
+}
+
+extern "C" int tc_attn_fwd_packed_q2(int dtype, const void *qkv, int ldq, const int32_t *blocks, int n_blocks,
+                                     int max_len, void *out, int H, int D, double flops, void *stream) {
+    TC_REQUIRE(dtype == TC_BF16, "tc_attn_fwd_packed_q2: bf16 only (dtype %d)", dtype);
+    return attn_fwd_packed_impl(dtype, qkv, ldq, blocks, n_blocks, max_len, out, H, D, flops, true, stream);
+}
+
+static int attn_fwd_packed_impl(int dtype, const void *qkv, int ldq, const int32_t *blocks, int n_blocks, int max_len,
+                                void *out, int H, int D, double flops, bool q2, void *stream) {
     TC_REQUIRE(dtype == TC_BF16 || dtype == TC_F32, "tc_attn_fwd_packed: bad dtype %d", dtype);
     TC_REQUIRE(qkv && out && blocks, "tc_attn_fwd_packed: null operand");
     TC_REQUIRE(D == 64, "tc_attn_fwd_packed: head_dim %d unsupported (only 64)", D);
@@ -564,17 +636,10 @@ extern "C" int tc_attn_fwd_packed(int dtype, const void *qkv, int ldq, const int
     TC_REQUIRE(grid < (1L << 31), "tc_attn_fwd_packed: grid too large");
     TcProfScope prof(TC_PROF_ATTN, s, flops);      // 4 * H * D * sum of T_s^2, known to the caller only
     if (dtype == TC_BF16) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bf16_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS_BYTES);
-            if (e != hipSuccess) {
-                tc_set_error("tc_attn_fwd_packed: hipFuncSetAttribute: %s", hipGetErrorString(e));
-                return TC_ELAUNCH;
-            }
-            attr_set = true;
-        }
-        TC_LAUNCH(attn_bf16_kernel, dim3((unsigned)grid), dim3(64 * kWaves), ATTN_LDS_BYTES, s, p);
+        const int rc = q2 ? attn_bf16_attr<true>("tc_attn_fwd_packed") : attn_bf16_attr<false>("tc_attn_fwd_packed");
+        if (rc != TC_OK) return rc;
+        if (q2) TC_LAUNCH(attn_bf16_kernel<true>, dim3((unsigned)grid), dim3(64 * kWaves), ATTN_LDS_BYTES, s, p);
+        else TC_LAUNCH(attn_bf16_kernel<false>, dim3((unsigned)grid), dim3(64 * kWaves), ATTN_LDS_BYTES, s, p);
     } else {
         TC_LAUNCH(attn_f32_kernel, dim3((unsigned)grid), dim3(64), 0, s, p);
     }

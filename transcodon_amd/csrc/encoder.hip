@@ -103,6 +103,12 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = B * T, E = d->E, F = d->F, dt = d->dtype;
     const bool bf = dt == TC_BF16;
+    // bf16: q leaves the q/k/v product scaled by log2(e) / sqrt(64), the base-2 form the attention kernel takes
+    const float q_scale = bf ? 0.125f * 1.4426950408889634f : 0.125f;
+    auto attn = [&]() {
+        return bf ? tc_attn_fwd_q2(dt, w.qkv, 3 * E, w.words, w.h, B, T, d->H, 64, stream)
+                  : tc_attn_fwd(dt, w.qkv, 3 * E, w.words, w.h, B, T, d->H, 64, stream);
+    };
     auto ln = [&](const float *g, const float *b, float *extra_f32) {
         return tc_layernorm_fwd(w.x, g, b, bf ? extra_f32 : static_cast<float *>(w.h),
                                 bf ? w.h : nullptr, M, E, d->ln_eps, stream);
@@ -157,8 +163,8 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
             // inside the q/k/v and fc1 products (modules.py:87,100)
             const bool last = l + 1 == d->num_layers;
             TC_TRY(tc_gemm_ln(dt, TC_EPI_QKV_ROPE, w.xb, E, lw.w_qkv_ln, lw.c_qkv_ln, lw.s_qkv_ln, w.ln_rows, w.qkv,
-                              3 * E, M, 3 * E, E, 0.125f, lw.rope_cos, lw.rope_sin, T, 64, stream));
-            TC_TRY(tc_attn_fwd(dt, w.qkv, 3 * E, w.words, w.h, B, T, d->H, 64, stream));
+                              3 * E, M, 3 * E, E, q_scale, lw.rope_cos, lw.rope_sin, T, 64, stream));
+            TC_TRY(attn());
             TC_TRY(tc_gemm_residual_split(dt, w.h, E, lw.w_o, lw.b_o, w.xb, x_lo, w.row_acc, E, M, E, E, stream));
             TC_TRY(tc_ln_rows_finalize(w.row_acc, w.ln_rows, M, E, d->ln_eps, stream));
             TC_TRY(tc_gemm_ln(dt, TC_EPI_BIAS_GELU, w.xb, E, lw.w_fc1_ln, lw.c_fc1_ln, lw.s_fc1_ln, w.ln_rows, w.mid,
@@ -173,8 +179,8 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
         }
         TC_TRY(ln(lw.ln1_g, lw.ln1_b, nullptr));
         TC_TRY(tc_gemm(dt, TC_EPI_QKV_ROPE, w.h, E, lw.w_qkv, lw.b_qkv, nullptr, w.qkv, 3 * E, M, 3 * E, E,
-                       0.125f, lw.rope_cos, lw.rope_sin, T, 64, stream));
-        TC_TRY(tc_attn_fwd(dt, w.qkv, 3 * E, w.words, w.h, B, T, d->H, 64, stream));
+                       q_scale, lw.rope_cos, lw.rope_sin, T, 64, stream));
+        TC_TRY(attn());
         TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.h, E, lw.w_o, lw.b_o, w.x, w.x, E, M, E, E, 0.f, nullptr,
                        nullptr, 0, 0, stream));
         TC_TRY(ln(lw.ln2_g, lw.ln2_b, nullptr));
@@ -268,9 +274,14 @@ extern "C" int tc_encoder_forward_packed(const tc_encoder_desc *d, const int32_t
     for (int l = 0; l < d->num_layers; ++l) {
         const tc_layer_weights &lw = d->layers[l];
         TC_TRY(ln(lw.ln1_g, lw.ln1_b, nullptr));
-        TC_TRY(tc_gemm_qkv_packed(dt, w.h, E, lw.w_qkv, lw.b_qkv, w.qkv, 3 * E, M, 3 * E, E, 0.125f, lw.rope_cos,
-                                  lw.rope_sin, pos, d->rope_table_len, 64, stream));
-        TC_TRY(tc_attn_fwd_packed(dt, w.qkv, 3 * E, attn_blocks, n_blocks, max_len, w.h, d->H, 64, attn_flops, stream));
+        // bf16: q scaled by log2(e) / sqrt(64) for the base-2 attention kernel
+        TC_TRY(tc_gemm_qkv_packed(dt, w.h, E, lw.w_qkv, lw.b_qkv, w.qkv, 3 * E, M, 3 * E, E,
+                                  bf ? 0.125f * 1.4426950408889634f : 0.125f, lw.rope_cos, lw.rope_sin, pos,
+                                  d->rope_table_len, 64, stream));
+        if (bf)
+            TC_TRY(tc_attn_fwd_packed_q2(dt, w.qkv, 3 * E, attn_blocks, n_blocks, max_len, w.h, d->H, 64, attn_flops, stream));
+        else
+            TC_TRY(tc_attn_fwd_packed(dt, w.qkv, 3 * E, attn_blocks, n_blocks, max_len, w.h, d->H, 64, attn_flops, stream));
         TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.h, E, lw.w_o, lw.b_o, w.x, w.x, E, M, E, E, 0.f, nullptr, nullptr, 0,
                        0, stream));
         TC_TRY(ln(lw.ln2_g, lw.ln2_b, nullptr));

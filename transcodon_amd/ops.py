@@ -87,13 +87,15 @@ def key_mask_words(pad_flags, B, T):
     return words
 
 
-def attention(qkv, B, T, H, key_words=None):
-    """qkv[B*T, 3*H*64] (q scaled, q/k rotated) -> out[B*T, H*64]."""
+def attention(qkv, B, T, H, key_words=None, q2=False):
+    """qkv[B*T, 3*H*64] (q scaled, q/k rotated) -> out[B*T, H*64].  q2: the q columns carry
+    log2(e) / sqrt(64) instead of 1 / sqrt(64) (tc_attn_fwd_q2, bf16 only)."""
     _dev(qkv, key_words)
     E = H * 64
     out = torch.empty(B * T, E, dtype=qkv.dtype, device=qkv.device)
-    check(_lib.load().tc_attn_fwd(_dt(qkv), _p(qkv), qkv.stride(0), _p(key_words), _p(out), B, T, H, 64,
-                                  _stream()), "tc_attn_fwd")
+    fn = _lib.load().tc_attn_fwd_q2 if q2 else _lib.load().tc_attn_fwd
+    check(fn(_dt(qkv), _p(qkv), qkv.stride(0), _p(key_words), _p(out), B, T, H, 64, _stream()),
+          "tc_attn_fwd_q2" if q2 else "tc_attn_fwd")
     return out
 
 
