@@ -1114,9 +1114,14 @@ constexpr bool piecewise_epilogue(int epi) {
     } while (0)
 #endif
 
+#ifndef TC_GEMM_EARLY
+#define TC_GEMM_EARLY 0
+#endif
+
 template <typename T, int EPI, bool FOLD = false>
 __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     using namespace k256x;
+    constexpr int kEarly = TC_GEMM_EARLY;      // MFMAs of a phase issued after its hand-over barrier
     static_assert(sizeof(T) == 2, "bf16 only");
     // Epilogues that read nothing from global memory (bias comes through LDS) run inside phase 0
     // of the next tile's first k-tile, after that phase's LDS-DMA issue and before its LDS reads:
@@ -1372,6 +1377,11 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             f32x4 bq[2][2][2];                   // [nq][column block][k-step]
             f32x4 af[4][2];                      // [row block][k-step] of the current mq
 
+            // A phase's 16 MFMAs, then the barrier that hands the matrix pipe to the other wave of the SIMD.
+            // TC_GEMM_EARLY = n enters that barrier n MFMAs before the end of the turn.  On bare MFMA turns that
+            // removes the wake-up gap of the released wave (tools/ubench/mfma_handover.hip: 256 -> 217 ns per 32
+            // MFMAs); here it costs 3-9 %, because the phase is bound by the load slot of the wave that is not
+            // multiplying, and the late MFMAs delay the start of that slot.
             auto math = [&](int mq, int nq) {
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1379,18 +1389,21 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
+                        for (int i = 0; i < 4; ++i) {
+                            if (kEarly > 0 && (ks * 2 + nb) * 4 + i == 16 - kEarly) TC_XBAR();
                             acc[nq * 2 + nb][mq * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                 __builtin_bit_cast(bf16x8, bq[nq][nb][ks]), __builtin_bit_cast(bf16x8, af[i][ks]),
                                 acc[nq * 2 + nb][mq * 4 + i], 0, 0, 0);
+                        }
                 __builtin_amdgcn_s_setprio(0);
+                if (kEarly == 0) TC_XBAR();
             };
             auto read_b = [&](int nq) {
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-#ifdef TC_ABL_NOREADS
+#if defined(TC_ABL_NOREADS) || defined(TC_ABL_NOREADS_B)
                         bq[nq][nb][ks] = f32x4{(float)kt, 1.f, 2.f, 3.f};
                         asm volatile("" : "+v"(bq[nq][nb][ks]));
 #else
@@ -1445,8 +1458,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             TC_PH(1);                              // reads issued
             TC_XBAR();
             TC_PH(2);                              // wait at barrier 1
-            math(0, 0);
-            TC_XBAR();
+            math(0, 0);                            // ends with the hand-over barrier
             TC_PH(3);                              // MFMA + barrier 2
             // ---- phase 1 ----
             const bool more = c2_tile < my_count;
@@ -1459,8 +1471,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             TC_PH(4);
             TC_XBAR();
             TC_PH(5);
-            math(0, 1);
-            TC_XBAR();
+            math(0, 1);                            // ends with the hand-over barrier
             TC_PH(6);
             // ---- phase 2 ----
             if (more) stage_half(cur + SLOT_A0, p.A, a0_src, koff2);
@@ -1471,8 +1482,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             TC_PH(7);
             TC_XBAR();
             TC_PH(8);
-            math(1, 1);
-            TC_XBAR();
+            math(1, 1);                            // ends with the hand-over barrier
             TC_PH(9);
             // ---- phase 3 ----
             // The wait leaves in flight what was issued after this k-tile's A1: three half-tiles,
@@ -1499,8 +1509,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             TC_PH(10);                             // DMA issue + vmcnt wait
             TC_XBAR();
             TC_PH(11);
-            math(1, 0);
-            TC_XBAR();
+            math(1, 0);                            // ends with the hand-over barrier
             TC_PH(12);
 #ifdef TC_GEMM_STAMPS
             TC_STAMP(s1);
