@@ -18,9 +18,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xffffffff, 0x00020000);
 }
 
-// MODE 0: CROSS, 1: SAME.  DO_MFMA / R / D select the work.
-// ALT modes: 2 = barrier after each half, wait for the pieces in every half; 3 = wait every 4th iteration;
-// 4 = no barrier between the halves; 5 = as 2 with bursts of 32 MFMAs (and twice the loads) per half
+// MODE 0: CROSS, 1: SAME.  DO_MFMA / R / D select the work.  (Turn-taking schedules are in mfma_handover.hip: they
+// need one code path for both wave groups, or hipcc copies the accumulators at every branch.)
 template <int MODE, bool DO_MFMA, int R, int D>
 __global__ __launch_bounds__(512) void k(float *out, const char *src, int iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -56,29 +55,6 @@ __global__ __launch_bounds__(512) void k(float *out, const char *src, int iters)
                     ++di;
                 }
             }
-        } else if (MODE >= 2) {
-            constexpr int kBurst = MODE == 5 ? 32 : 16, kMul = MODE == 5 ? 2 : 1;
-            // the alternating schedule: the two wave groups swap roles every half iteration, a barrier after each half;
-            // MODE 3 waits for its direct-to-LDS pieces only every fourth iteration (a prefetch distance)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if ((wid < 4) == (half == 0)) {
-#pragma unroll
-                    for (int m = 0; m < kBurst; ++m)
-                        if (DO_MFMA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m & 15]) : "v"(a), "v"(b));
-                } else {
-#pragma unroll
-                    for (int di = 0; di < kMul * D / 2; ++di)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(my_lds + 1024 * (di & 7) + 4096), 16, lane * 16, goff + di * 1024, 0, 0);
-#pragma unroll
-                    for (int ri = 0; ri < kMul * R / 2; ++ri)
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(frag[ri & 3]) : "v"(rd), "n"(0));
-                    if (MODE != 3 || (i & 3) == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(frag[0]), "+v"(frag[1]), "+v"(frag[2]), "+v"(frag[3])::"memory");
-                }
-                if (MODE != 4 || half == 1) __builtin_amdgcn_s_barrier();
-            }
-            continue;
         } else {
             if (mfma_wave) {
 #pragma unroll
@@ -128,13 +104,8 @@ static void row(float *out, const char *src) {
     const float m0 = run<0, true, 0, 0>(out, src);
     const float lc = run<0, false, R, D>(out, src), ls = run<1, false, R, D>(out, src);
     const float bc = run<0, true, R, D>(out, src), bs = run<1, true, R, D>(out, src);
-    const float a0 = run<2, true, 0, 0>(out, src), a2 = run<2, true, R, D>(out, src), a3 = run<3, true, R, D>(out, src);
-    const float n0 = run<4, true, 0, 0>(out, src), n2 = run<4, true, R, D>(out, src);
-    const float b0 = run<5, true, 0, 0>(out, src) / 2, b2 = run<5, true, R, D>(out, src) / 2;
-    printf("R=%2d reads D=%2d pieces per 32 MFMAs:  MFMA only %6.3f | loads only: cross %6.3f same %6.3f | both: cross %6.3f same %6.3f | "
-           "alternating: MFMA only %6.3f, both %6.3f, both with a wait every 4th %6.3f | no barrier between halves: %6.3f, %6.3f | "
-           "bursts of 32 (per 32 MFMAs): %6.3f, %6.3f ms\n",
-           R, D, m0, lc, ls, bc, bs, a0, a2, a3, n0, n2, b0, b2);
+    printf("R=%2d reads D=%2d pieces per 32 MFMAs:  MFMA only %6.3f | loads only: cross %6.3f same %6.3f | both: cross %6.3f same %6.3f ms\n",
+           R, D, m0, lc, ls, bc, bs);
 }
 
 int main() {
