@@ -32,8 +32,10 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--q2", action="store_true", help="time the new library's base-2 entry (tc_attn_fwd_q2)")
+    ap.add_argument("--q2-base", action="store_true", help="... and the base library's too")
     a = ap.parse_args()
-    libs = {"base": load(a.base), "new": load(a.new, a.q2)}
+    q2 = {"base": a.q2_base, "new": a.q2 or a.q2_base}
+    libs = {"base": load(a.base, q2["base"]), "new": load(a.new, q2["new"])}
     H, E = 12, 768
     strm = torch.cuda.current_stream().cuda_stream
     for shp in a.shapes.split(","):
@@ -47,7 +49,7 @@ def main():
         outs = {k: torch.empty(B * T, E, device="cuda", dtype=torch.bfloat16) for k in libs}
 
         def run(k):
-            src = qkv2 if (k == "new" and a.q2) else qkv
+            src = qkv2 if q2[k] else qkv
             assert libs[k](1, src.data_ptr(), 3 * E, None, outs[k].data_ptr(), B, T, H, 64, strm) == 0
 
         for k in libs:

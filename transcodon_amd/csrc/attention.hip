@@ -224,6 +224,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_bf16_kernel(const AttnPar
         // the first MFMA of each chain takes a constant as its C operand: 0 (no accumulator clearing), or
         // minus the running offset (Q2)
         f32x16 acc_s[2];
+        uint32_t p_pk[2][8];                       // Q2: P as bf16 pairs
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -290,16 +291,20 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_bf16_kernel(const AttnPar
 #pragma unroll
                 for (int r = 0; r < 16; ++r) negm16[r] = nm;
             }
+            // P is packed to bf16 pairs at once (the form P.V multiplies) and the row sum is taken over those
+            // rounded values: one dot-product instruction per pair instead of two adds, and numerator and
+            // denominator of the softmax see the same P
+            const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3F803F80u);
             float lsum0 = 0.f, lsum1 = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const float e0 = __builtin_amdgcn_exp2f(acc_s[kb][r]), e1 = __builtin_amdgcn_exp2f(acc_s[kb][r + 1]);
-                    acc_s[kb][r] = e0;
-                    acc_s[kb][r + 1] = e1;
-                    lsum0 += e0;
-                    lsum1 += e1;
+                    const uint32_t w = tc_pack_bf16(e0, e1);
+                    p_pk[kb][r >> 1] = w;
+                    if (kb == 0) lsum0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w), ones, lsum0, false);
+                    else lsum1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w), ones, lsum1, false);
                 }
             l_run += lsum0 + lsum1;
         } else {
@@ -340,8 +345,12 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_bf16_kernel(const AttnPar
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 pf;
+                if constexpr (Q2) {
+                    pf = __builtin_bit_cast(bf16x8, u32x4{p_pk[kb][4 * s], p_pk[kb][4 * s + 1], p_pk[kb][4 * s + 2], p_pk[kb][4 * s + 3]});
+                } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (__bf16)acc_s[kb][8 * s + j];
+                    for (int j = 0; j < 8; ++j) pf[j] = (__bf16)acc_s[kb][8 * s + j];
+                }
                 // The transposing reads are issued from assembly: through the builtin the compiler
                 // cannot tell them from the LDS-DMA writes of the next tile in flight and waits for
                 // that prefetch (vmcnt(0)) in the middle of every iteration.
