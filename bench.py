@@ -318,7 +318,9 @@ def bench_varlen(args, world, rank, dev, dist_on, rccl_ranks=1):
                        "n_seqs": n_total, "tokens": int(lens_all.sum()), "mean_len": round(float(lens_all.mean()), 1),
                        "batches_per_step_rank0": len(prepared), "parallelism": f"sequence-sharded x{world}",
                        "rccl_ranks": rccl_ranks, "backend": args.backend if world > 1 else None, "seqs_per_s": round(n_total * args.steps / elapsed, 1),
-                       "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3)},
+                       "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3),
+                       "hip_graph_ms_per_step": graph_ms and round(graph_ms, 3),
+                       "hip_graph_error": graph_err},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel / gemm256_kernel (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n,
@@ -552,6 +554,29 @@ def main():
     lib.tc_prof_enable(0)
     elapsed, bases = timed(args.steps)                      # the headline: no per-kernel timers
     elapsed_io, _ = timed(args.steps, host_io=True)         # the same with H2D of the inputs and D2H of the bases
+    # the same step with the forward replayed from one HIP graph (reported beside the headline, never as it)
+    graph_ms = graph_err = None
+    if args.config == 2:
+        try:
+            graphed = model.capture_forward(B, T)
+            tok0, sp0, aa0, offs0, row00 = mbs[0][:5]
+
+            def graph_step():
+                out = graphed(tok0, sp0, check_indices=False)
+                return ops.codon_decode(out["logits"].view(B * T, -1), aa0, offs0, row00)
+
+            same = bool(torch.equal(graph_step(), bases))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                graph_step()
+            torch.cuda.synchronize()
+            graph_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+            if not same:
+                graph_err = "decoded bases differ from the eager step"
+            del graphed
+        except Exception as e:                   # a refused capture must not take the bench line with it
+            graph_err = f"{type(e).__name__}: {e}"
     lib.tc_prof_reset()
     lib.tc_prof_enable(1)
     elapsed_prof, _ = timed(args.steps)                     # instrumented pass: per-kernel device times
@@ -615,7 +640,9 @@ def main():
                        "layernorm": ("24 of 25 folded into the q/k/v, out-proj, fc1 and fc2 products, residual stream as bf16 hi/lo planes" if folded
                                      else "separate kernels"),
                        "with_host_io_tokens_per_s": round(tokens_total / elapsed_io, 1),
-                       "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3)},
+                       "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3),
+                       "hip_graph_ms_per_step": graph_ms and round(graph_ms, 3),
+                       "hip_graph_error": graph_err},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel<bf16, EPI> (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),

@@ -6,7 +6,7 @@ ProteinBertModel and its sub-modules, embed_sequence) over hand-written HIP kern
 """
 
 from .alphabet import Alphabet, BatchConverter, ORGANISM2ID  # noqa: F401
-from .model import ProteinBertModel  # noqa: F401
+from .model import GraphedForward, ProteinBertModel  # noqa: F401
 from .modules import (ESM1bLayerNorm, RNA_2D_RobertaLMHead, RobertaLMHead,  # noqa: F401
                       TransformerLayer, gelu)
 from .multihead_attention import MultiheadAttention  # noqa: F401

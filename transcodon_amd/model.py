@@ -231,7 +231,7 @@ class ProteinBertModel(nn.Module):
         return ws
 
     # -- forward ---------------------------------------------------------------------------
-    def forward(self, tokens, species_type_ids, repr_layers=[12], need_head_weights=False):
+    def forward(self, tokens, species_type_ids, repr_layers=[12], need_head_weights=False, _defer_status=None):
         assert tokens.ndim == 2
         if not tokens.is_cuda:
             raise _lib.HipLibraryError(
@@ -268,9 +268,17 @@ class ProteinBertModel(nn.Module):
             struct.data_ptr(), reps[L].data_ptr() if L in reps else None, len(mids), rep_idx,
             rep_ptr, status.data_ptr(), ws.data_ptr(), ws.numel(),
             torch.cuda.current_stream().cuda_stream), "tc_encoder_forward")
+        out = {"logits": logits, "struct_label_output": struct, "representations": reps}
+        if _defer_status is not None:           # a graph capture in progress: no host read of the flag here
+            _defer_status.append(status)
+            return out
         if self.check_indices and int(status.item()) != 0:
             raise IndexError("token or species id out of range")
-        return {"logits": logits, "struct_label_output": struct, "representations": reps}
+        return out
+
+    def capture_forward(self, B, T, repr_layers=(12,), device=None):
+        """The inference forward of a fixed batch shape as ONE HIP graph (see GraphedForward)."""
+        return GraphedForward(self, B, T, repr_layers, device)
 
     def packed_layout(self, species_type_ids, cu_seqlens, device):
         """Device-side index arrays of a packed batch (see forward_packed): rotary position and species
@@ -397,3 +405,48 @@ def _flag(v):
     if isinstance(v, bool):
         return v
     return str(v).strip().lower() not in ("0", "false", "no", "off", "")
+
+
+class GraphedForward:
+    """``ProteinBertModel.forward`` (model.py:175-259, inference, no attention weights) for one fixed
+    batch shape, captured into a HIP graph: the ~150 kernel launches of a forward become one graph
+    launch, which is what a small batch's latency consists of.  Calling it copies the inputs into the
+    graph's static buffers, replays the graph and returns the same dict as ``forward``; the tensors in
+    it are the graph's own output buffers and are overwritten by the next call (clone what must live
+    longer).  Weights are read at replay time, so ``load_state_dict`` into the same parameters needs no
+    new capture; ``set_compute_dtype`` or another shape does."""
+
+    def __init__(self, model, B, T, repr_layers=(12,), device=None):
+        dev = torch.device(device) if device is not None else next(model.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.HipLibraryError("GraphedForward needs the model on the GPU (there is no CPU fallback)")
+        self.model, self.B, self.T = model, int(B), int(T)
+        self.tokens = torch.full((self.B, self.T), model.padding_idx, dtype=torch.int32, device=dev)
+        self.tokens[:, 0] = model.cls_idx
+        self.species = torch.zeros(self.B, dtype=torch.int32, device=dev)
+        repr_layers = list(repr_layers)
+        with torch.no_grad():
+            # first calls outside the capture: weight packing, workspace, one-time kernel attributes
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    model(self.tokens, self.species, repr_layers=repr_layers)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            deferred = []
+            with torch.cuda.graph(self.graph):
+                self.out = model(self.tokens, self.species, repr_layers=repr_layers, _defer_status=deferred)
+            self.status = deferred[0]
+
+    def __call__(self, tokens, species_type_ids, check_indices=None):
+        if tuple(tokens.shape) != (self.B, self.T):
+            raise ValueError(f"GraphedForward was captured for tokens of shape {(self.B, self.T)}, got {tuple(tokens.shape)}")
+        self.tokens.copy_(tokens)
+        self.species.copy_(species_type_ids.reshape(-1))
+        self.graph.replay()
+        chk = self.model.check_indices if check_indices is None else check_indices
+        if chk and int(self.status.item()) != 0:
+            raise IndexError("token or species id out of range")
+        return self.out
