@@ -21,8 +21,11 @@ this process a launcher: before anything touches the GPU it starts N copies of i
 GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, and returns their exit
 status.  Every rank runs its own batch (no data-path collective), the slowest rank's time is used.
 
-Rank 0 prints ONE JSON line.  `value` comes from steps timed with the per-kernel timers OFF; a
-second pass of the same steps with the timers on gives the per-kernel numbers.  `roofline`
+Rank 0 prints ONE JSON line.  `value` comes from steps timed with the per-kernel timers OFF, the
+forward of each full micro-batch replayed from one captured HIP graph (the same kernels with the
+same arguments as the eager call, recorded once by ProteinBertModel.capture_forward; --no-graph
+launches them one by one, and `config.eager_ms_per_step` always reports that form); a further pass
+of eager steps with the timers on gives the per-kernel numbers.  `roofline`
 describes the dominant kernel family (the MFMA GEMM): achieved = algorithmic FLOPs (2*M*N*K
 summed over its launches) / summed device time of those launches, from HIP events attached to
 every GEMM dispatch; `roofline_by_kernel` has the same for the other families.  `cpu_baseline` is
@@ -319,7 +322,9 @@ def bench_varlen(args, world, rank, dev, dist_on, rccl_ranks=1):
                        "batches_per_step_rank0": len(prepared), "parallelism": f"sequence-sharded x{world}",
                        "rccl_ranks": rccl_ranks, "backend": args.backend if world > 1 else None, "seqs_per_s": round(n_total * args.steps / elapsed, 1),
                        "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3),
-                       "hip_graph_ms_per_step": graph_ms and round(graph_ms, 3),
+                       "launch": ("one HIP graph per forward (ProteinBertModel.capture_forward), decode kernel eager"
+                                  if graphed is not None else "eager, kernel by kernel"),
+                       "eager_ms_per_step": round(1e3 * elapsed_eager / args.steps, 3),
                        "hip_graph_error": graph_err},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel / gemm256_kernel (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -430,6 +435,8 @@ def main():
                     help="train = --config 4 (kept for older command lines)")
     ap.add_argument("--train-batch", type=int, default=64)
     ap.add_argument("--train-seq-len", type=int, default=1024)
+    ap.add_argument("--no-graph", action="store_true",
+                    help="inference configs: launch the forward kernel by kernel instead of replaying the captured HIP graph")
     ap.add_argument("--no-fold", action="store_true",
                     help="inference configs: run the LayerNorms of the layers as separate kernels")
     ap.add_argument("--struct-labels", action="store_true",
@@ -514,19 +521,31 @@ def main():
                     (d["offs"][lo_s:hi_s + 1] - a0).contiguous(), (d["row0"][lo_s:hi_s] - lo_s * T).contiguous(),
                     a0, a1))
 
-    def micro(i):
+    # The forward of a full micro-batch is replayed from one HIP graph (ProteinBertModel.capture_forward: the same
+    # launches, recorded once); a refused capture falls back to the eager call and says so in the result.
+    graphed, graph_err = None, None
+    if not args.no_graph:
+        try:
+            graphed = model.capture_forward(B, T)
+        except Exception as e:
+            graph_err = f"{type(e).__name__}: {e}"
+
+    def micro(i, use_graph):
         """Forward + decode of micro-batch i of this rank's shard; returns the decoded bases."""
         tok_i, sp_i, aa_i, offs_i, row0_i, a0, a1 = mbs[i]
-        with torch.no_grad():
-            out = model(tok_i, sp_i)
+        if use_graph and graphed is not None and tok_i.shape[0] == B:
+            out = graphed(tok_i, sp_i, check_indices=False)
+        else:
+            with torch.no_grad():
+                out = model(tok_i, sp_i)
         return ops.codon_decode(out["logits"].view(tok_i.shape[0] * T, -1), aa_i, offs_i, row0_i), a0, a1
 
-    def step(host_io=False):
+    def step(host_io=False, use_graph=True):
         if host_io:      # token ids, species and residues come from the host; decoded bases go back
             for k in ("tok", "sp", "aa", "offs", "row0"):
                 d[k].copy_(host[k], non_blocking=True)
         for i in range(n_micro):
-            bases, a0, a1 = micro(i)
+            bases, a0, a1 = micro(i, use_graph)
             if host_io:
                 bases_host[3 * a0:3 * a1].copy_(bases, non_blocking=True)
         return bases
@@ -554,32 +573,13 @@ def main():
     lib.tc_prof_enable(0)
     elapsed, bases = timed(args.steps)                      # the headline: no per-kernel timers
     elapsed_io, _ = timed(args.steps, host_io=True)         # the same with H2D of the inputs and D2H of the bases
-    # the same step with the forward replayed from one HIP graph (reported beside the headline, never as it)
-    graph_ms = graph_err = None
-    if args.config == 2:
-        try:
-            graphed = model.capture_forward(B, T)
-            tok0, sp0, aa0, offs0, row00 = mbs[0][:5]
-
-            def graph_step():
-                out = graphed(tok0, sp0, check_indices=False)
-                return ops.codon_decode(out["logits"].view(B * T, -1), aa0, offs0, row00)
-
-            same = bool(torch.equal(graph_step(), bases))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                graph_step()
-            torch.cuda.synchronize()
-            graph_ms = 1e3 * (time.perf_counter() - t0) / args.steps
-            if not same:
-                graph_err = "decoded bases differ from the eager step"
-            del graphed
-        except Exception as e:                   # a refused capture must not take the bench line with it
-            graph_err = f"{type(e).__name__}: {e}"
+    elapsed_eager, bases_eager = timed(args.steps, use_graph=False)   # the same step launched kernel by kernel
+    if graphed is not None and not torch.equal(bases_eager, bases):
+        raise SystemExit(f"bench: the graph replay and the eager step decode different bases "
+                         f"({int((bases_eager != bases).sum())} of {bases.numel()})")
     lib.tc_prof_reset()
     lib.tc_prof_enable(1)
-    elapsed_prof, _ = timed(args.steps)                     # instrumented pass: per-kernel device times
+    elapsed_prof, _ = timed(args.steps, use_graph=False)    # instrumented pass (eager launches): per-kernel device times
     lib.tc_prof_enable(0)
     prof = {name: _lib.prof_collect(kind) for name, kind in
             (("gemm", _lib.PROF_GEMM), ("attn", _lib.PROF_ATTN), ("layernorm", _lib.PROF_LAYERNORM),
@@ -641,7 +641,9 @@ def main():
                                      else "separate kernels"),
                        "with_host_io_tokens_per_s": round(tokens_total / elapsed_io, 1),
                        "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3),
-                       "hip_graph_ms_per_step": graph_ms and round(graph_ms, 3),
+                       "launch": ("one HIP graph per forward (ProteinBertModel.capture_forward), decode kernel eager"
+                                  if graphed is not None else "eager, kernel by kernel"),
+                       "eager_ms_per_step": round(1e3 * elapsed_eager / args.steps, 3),
                        "hip_graph_error": graph_err},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel<bf16, EPI> (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -387,6 +387,12 @@ int tc_gemm_residual_ln(int dtype, const void *A, int lda, const void *W, const 
                         void *out, void *out_bf16, unsigned long long *row_acc, int ldo, int M, int N, int K,
                         void *stream);
 int tc_ln_rows_finalize(unsigned long long *row_acc, float *ln_rows, int M, int E, float eps, void *stream);
+/* dst[0..n) = src[0..n) (f32, n a multiple of 4, 16-byte aligned) as a kernel launch: what the forward copies
+ * representations with.  On this stack the memset and copy nodes of a captured graph are not ordered against the
+ * graph's previous launch, kernel nodes are. */
+int tc_copy_f32(float *dst, const float *src, long n, void *stream);
+/* row_acc [M,2] to zero, as a kernel launch (what a forward starts with; graph-capture safe) */
+int tc_ln_rows_clear(unsigned long long *row_acc, int M, void *stream);
 int tc_gemm_ln(int dtype, int epilogue, const void *A, int lda, const void *Wf, const float *c, const float *s,
                const float *ln_rows, void *out, int ldo, int M, int N, int K, float q_scale, const float *rope_cos,
                const float *rope_sin, int T, int head_dim, void *stream);

@@ -545,3 +545,27 @@ def test_graph_captured_forward_equals_eager(full_f32, full_bf16, dtype):
     graphed(tok_d, sp_d)                                   # and the graph is usable again afterwards
     with pytest.raises(ValueError):
         graphed(tok_d[:, :50], sp_d)
+
+
+def test_graph_replays_back_to_back_with_folded_layernorms(full_bf16):
+    """Replays launched one after the other with no host synchronisation in between, at a shape that takes
+    the folded-LayerNorm path (its row accumulators are cleared at the start of every forward, by a kernel:
+    a memset node was not ordered against the previous launch of the graph and cleared sums still in use),
+    and with inner representations (copied by a kernel for the same reason): every replay equals eager."""
+    rng = np.random.default_rng(17)
+    B, T = 64, 512
+    from transcodon_amd import _lib
+    assert _lib.load().tc_ln_fold_supported(_lib.TC_BF16, B, T, 768, 3072) != 0
+    tok = np.stack([[O.CLS] + list(rng.choice([5, 6, 7, 8, 9], T - 2)) + [O.EOS] for _ in range(B)])
+    sp = rng.integers(0, 1438, B)
+    tok_d, sp_d = torch.from_numpy(tok).to(DEV), torch.from_numpy(sp).to(DEV)
+    with torch.no_grad():
+        eager = full_bf16(tok_d, sp_d, repr_layers=[3, 12])
+    graphed = full_bf16.capture_forward(B, T, repr_layers=[3, 12])
+    for n in (1, 3, 2):
+        for _ in range(n):
+            got = graphed(tok_d, sp_d, check_indices=False)
+        logits, r3 = got["logits"].clone(), got["representations"][3].clone()
+        torch.cuda.synchronize()
+        assert torch.equal(logits, eager["logits"]), n
+        assert torch.equal(r3, eager["representations"][3]), n

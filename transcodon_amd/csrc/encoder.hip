@@ -100,7 +100,6 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
         TC_REQUIRE(rep_layer && rep_out && rep_layer[i] >= 0 && rep_layer[i] < d->num_layers && rep_out[i],
                    "tc_encoder_forward: bad representation request %d", i);
 
-    hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = B * T, E = d->E, F = d->F, dt = d->dtype;
     const bool bf = dt == TC_BF16;
     // bf16: q leaves the q/k/v product scaled by log2(e) / sqrt(64), the base-2 form the attention kernel takes
@@ -122,11 +121,7 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
                     TC_TRY(tc_split_to_f32(w.xb, x_lo, rep_out[i], (long)M * E, stream));
                     continue;
                 }
-                hipError_t e = hipMemcpyAsync(rep_out[i], w.x, (size_t)M * E * 4, hipMemcpyDeviceToDevice, s);
-                if (e != hipSuccess) {
-                    tc_set_error("tc_encoder_forward: representation copy: %s", hipGetErrorString(e));
-                    return TC_ELAUNCH;
-                }
+                TC_TRY(tc_copy_f32(rep_out[i], w.x, (long)M * E, stream));
             }
         return TC_OK;
     };
@@ -139,11 +134,8 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
         fold = lw.w_qkv_ln && lw.c_qkv_ln && lw.s_qkv_ln && lw.w_fc1_ln && lw.c_fc1_ln && lw.s_fc1_ln;
     }
     if (fold) {
-        hipError_t e = hipMemsetAsync(w.row_acc, 0, w.rows_pad * 16, s);
-        if (e != hipSuccess) {
-            tc_set_error("tc_encoder_forward: clearing the row accumulators: %s", hipGetErrorString(e));
-            return TC_ELAUNCH;
-        }
+        // (a kernel: a memset node of a captured graph is not ordered against the graph's previous launch)
+        TC_TRY(tc_ln_rows_clear(w.row_acc, (int)w.rows_pad, stream));
         TC_TRY(tc_embed_fwd_ln(tokens, species, d->tok_table, d->species_table, nullptr, w.pad, status, B, T, E, d->vocab,
                                d->n_species, d->pad_idx, w.xb, x_lo, w.ln_rows, d->ln_eps, stream));
     } else {
@@ -199,11 +191,7 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
     } else {
         TC_TRY(tc_layernorm_fwd(w.x, d->lnf_g, d->lnf_b, static_cast<float *>(w.h), nullptr, M, E, d->ln_eps, stream));
         if (rep_last) {
-            hipError_t e = hipMemcpyAsync(rep_last, w.h, (size_t)M * E * 4, hipMemcpyDeviceToDevice, s);
-            if (e != hipSuccess) {
-                tc_set_error("tc_encoder_forward: representation copy: %s", hipGetErrorString(e));
-                return TC_ELAUNCH;
-            }
+            TC_TRY(tc_copy_f32(rep_last, static_cast<const float *>(w.h), (long)M * E, stream));
         }
     }
     const int nheads = struct_logits ? 2 : 1;
@@ -297,12 +285,7 @@ extern "C" int tc_encoder_forward_packed(const tc_encoder_desc *d, const int32_t
         float *dst = logits ? static_cast<float *>(w.h) : rep_last;      // embedding extraction writes the result directly
         TC_TRY(tc_layernorm_fwd(w.x, d->lnf_g, d->lnf_b, dst, nullptr, M, E, d->ln_eps, stream));
         if (rep_last && dst != rep_last) {
-            hipError_t e = hipMemcpyAsync(rep_last, w.h, (size_t)M * E * 4, hipMemcpyDeviceToDevice,
-                                          static_cast<hipStream_t>(stream));
-            if (e != hipSuccess) {
-                tc_set_error("tc_encoder_forward_packed: representation copy: %s", hipGetErrorString(e));
-                return TC_ELAUNCH;
-            }
+            TC_TRY(tc_copy_f32(rep_last, static_cast<const float *>(w.h), (long)M * E, stream));
         }
     }
     if (!logits) return TC_OK;              // embedding extraction needs no head

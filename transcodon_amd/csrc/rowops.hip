@@ -96,6 +96,20 @@ __global__ __launch_bounds__(256) void ln_rows_finalize_kernel(unsigned long lon
     *reinterpret_cast<f32x2 *>(ln_rows + 2L * row) = f32x2{rstd, (float)(-(double)rstd * mean)};
 }
 
+// Row accumulators to zero.  A kernel, not hipMemsetAsync: in a captured graph the memset node is not ordered
+// against the previous launch of the same graph, so back-to-back replays cleared the sums of the forward
+// still running.
+__global__ __launch_bounds__(256) void ln_rows_clear_kernel(unsigned long long *__restrict__ row_acc, long n2) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n2; i += (long)gridDim.x * 256)
+        *reinterpret_cast<u32x4 *>(row_acc + 2 * i) = u32x4{0u, 0u, 0u, 0u};
+}
+
+// Device-to-device copy of f32 data as a kernel (for the same reason: copy nodes of a captured graph)
+__global__ __launch_bounds__(256) void copy_f32_kernel(const float *__restrict__ src, float *__restrict__ dst, long n4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+        *reinterpret_cast<f32x4 *>(dst + 4 * i) = *reinterpret_cast<const f32x4 *>(src + 4 * i);
+}
+
 // x = hi + lo of the split residual stream as f32 (representations of inner layers)
 __global__ __launch_bounds__(256) void split_to_f32_kernel(const uint16_t *__restrict__ hi, const uint16_t *__restrict__ lo,
                                                            float *__restrict__ out, long n4) {
@@ -668,6 +682,24 @@ extern "C" int tc_ln_rows_finalize(unsigned long long *row_acc, float *ln_rows, 
     TcProfScope prof(TC_PROF_LN_ROWS, s, (double)M * 40.0);        // 16 B read, 16 B cleared, 8 B written per row
     TC_LAUNCH(ln_rows_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, row_acc, ln_rows, M, E, eps);
     TC_CHECK_LAUNCH("tc_ln_rows_finalize");
+    return TC_OK;
+}
+
+extern "C" int tc_copy_f32(float *dst, const float *src, long n, void *stream) {
+    TC_REQUIRE(dst && src && n > 0 && n % 4 == 0 && tc_aligned16(dst) && tc_aligned16(src), "tc_copy_f32: bad operand");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long n4 = n / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536);
+    TC_LAUNCH(copy_f32_kernel, dim3(grid), dim3(256), 0, s, src, dst, n4);
+    TC_CHECK_LAUNCH("tc_copy_f32");
+    return TC_OK;
+}
+
+extern "C" int tc_ln_rows_clear(unsigned long long *row_acc, int M, void *stream) {
+    TC_REQUIRE(row_acc && M > 0 && tc_aligned16(row_acc), "tc_ln_rows_clear: bad operand");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TC_LAUNCH(ln_rows_clear_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, row_acc, (long)M);
+    TC_CHECK_LAUNCH("tc_ln_rows_clear");
     return TC_OK;
 }
 
