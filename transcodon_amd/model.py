@@ -436,7 +436,9 @@ class GraphedForward:
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
             deferred = []
-            with torch.cuda.graph(self.graph):
+            # thread-local capture mode: other threads of the process (a collective library's watchdog, a data
+            # loader) may call into the runtime while this thread records
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.out = model(self.tokens, self.species, repr_layers=repr_layers, _defer_status=deferred)
             self.status = deferred[0]
 
