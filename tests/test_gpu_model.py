@@ -569,3 +569,30 @@ def test_graph_replays_back_to_back_with_folded_layernorms(full_bf16):
         torch.cuda.synchronize()
         assert torch.equal(logits, eager["logits"]), n
         assert torch.equal(r3, eager["representations"][3]), n
+
+
+def test_headline_size_determinism_and_batch_permutation(full_bf16):
+    """At the headline size (256 sequences x 512 tokens, the folded-LayerNorm kernels): two forwards of the same
+    batch are bit-identical (the fold's row sums are integer atomics, nothing else accumulates across
+    workgroups), and a permutation of the sequences permutes the outputs bit for bit (no result depends on a
+    row's place in a tile or on its neighbours); padded rows stay out of it."""
+    rng = np.random.default_rng(23)
+    B, T = 256, 512
+    tok = np.full((B, T), O.PAD, np.int64)
+    for b in range(B):
+        n = T if b % 3 else int(rng.integers(40, T))
+        tok[b, :n] = [O.CLS] + list(rng.choice([5, 6, 7, 8, 9], n - 2)) + [O.EOS]
+    sp = rng.integers(0, 1438, B)
+    perm = rng.permutation(B)
+    tok_d, sp_d = torch.from_numpy(tok).to(DEV), torch.from_numpy(sp).to(DEV)
+    perm_d = torch.from_numpy(perm).to(DEV)
+    with torch.no_grad():
+        a = full_bf16(tok_d, sp_d)
+        logits_a, rep_a = a["logits"].clone(), a["representations"][12].clone()
+        b = full_bf16(tok_d, sp_d)
+        assert torch.equal(b["logits"], logits_a) and torch.equal(b["representations"][12], rep_a)
+        c = full_bf16(tok_d[perm_d], sp_d[perm_d])
+    keep = (tok_d[perm_d] != O.PAD)
+    assert torch.equal(c["logits"][keep], logits_a[perm_d][keep])
+    assert torch.equal(c["representations"][12][keep], rep_a[perm_d][keep])
+    assert torch.isfinite(logits_a[tok_d != O.PAD]).all()
