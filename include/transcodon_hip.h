@@ -397,6 +397,9 @@ int tc_gemm_ln(int dtype, int epilogue, const void *A, int lda, const void *Wf, 
                const float *ln_rows, void *out, int ldo, int M, int N, int K, float q_scale, const float *rope_cos,
                const float *rope_sin, int T, int head_dim, void *stream);
 int tc_ln_fold_supported(int dtype, int B, int T, int E, int F);
+/* the same for the products without a rotary epilogue only (out-proj, fc1, fc2) on M rows: what the packed
+ * forward asks before it folds the second LayerNorm of every layer and keeps the residual stream as planes */
+int tc_ln_fold_rows_supported(int dtype, long M, int E, int F);
 
 /* ---- whole-encoder convenience (one call per forward) ---------------------------- */
 

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "tc_gemm_residual_ln": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                       C.c_int, vp]),
     "tc_ln_fold_supported": (C.c_int, [C.c_int] * 5),
+    "tc_ln_fold_rows_supported": (C.c_int, [C.c_int, C.c_long, C.c_int, C.c_int]),
     "tc_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "tc_gemm": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
                           C.c_int, C.c_int, C.c_float, vp, vp, C.c_int, C.c_int, vp]),

@@ -256,36 +256,67 @@ extern "C" int tc_encoder_forward_packed(const tc_encoder_desc *d, const int32_t
                        lw.w_fc1 && lw.b_fc1 && lw.w_fc2 && lw.b_fc2 && lw.rope_cos && lw.rope_sin,
                    "tc_encoder_forward_packed: layer %d has a null weight pointer", l);
     }
-    // one "sequence" per row for the gather: species_row[m] is the species of row m's sequence
-    TC_TRY(tc_embed_fwd(tokens, species_row, d->tok_table, d->species_table, w.x, nullptr, status, M, 1, E, d->vocab,
-                        d->n_species, d->pad_idx, stream));
-    for (int l = 0; l < d->num_layers; ++l) {
+    // Large bf16 batches whose layers carry the folded fc1 weights: the residual stream is the bf16 plane pair
+    // (w.xb, w.x), the second LayerNorm of every layer is applied inside fc1 (modules.py:100-101) from the row
+    // sums the out-proj epilogue leaves, and only the first LayerNorm stays a kernel (the packed q/k/v product
+    // gathers its rotary factors per row and has no folded form).
+    bool fold2 = bf && tc_ln_fold_rows_supported(dt, M, E, F) != 0;
+    for (int l = 0; l < d->num_layers && fold2; ++l) {
         const tc_layer_weights &lw = d->layers[l];
-        TC_TRY(ln(lw.ln1_g, lw.ln1_b, nullptr));
-        // bf16: q scaled by log2(e) / sqrt(64) for the base-2 attention kernel
-        TC_TRY(tc_gemm_qkv_packed(dt, w.h, E, lw.w_qkv, lw.b_qkv, w.qkv, 3 * E, M, 3 * E, E,
-                                  bf ? 0.125f * 1.4426950408889634f : 0.125f, lw.rope_cos, lw.rope_sin, pos,
-                                  d->rope_table_len, 64, stream));
-        if (bf)
-            TC_TRY(tc_attn_fwd_packed_q2(dt, w.qkv, 3 * E, attn_blocks, n_blocks, max_len, w.h, d->H, 64, attn_flops, stream));
-        else
-            TC_TRY(tc_attn_fwd_packed(dt, w.qkv, 3 * E, attn_blocks, n_blocks, max_len, w.h, d->H, 64, attn_flops, stream));
-        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.h, E, lw.w_o, lw.b_o, w.x, w.x, E, M, E, E, 0.f, nullptr, nullptr, 0,
-                       0, stream));
-        TC_TRY(ln(lw.ln2_g, lw.ln2_b, nullptr));
-        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_GELU, w.h, E, lw.w_fc1, lw.b_fc1, nullptr, w.mid, w.ld_mid, M, F, E, 0.f, nullptr,
-                       nullptr, 0, 0, stream));
-        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.x, w.x, E, M, E, F, 0.f, nullptr,
-                       nullptr, 0, 0, stream));
+        fold2 = lw.w_fc1_ln && lw.c_fc1_ln && lw.s_fc1_ln;
     }
-    if (bf) {
-        TC_TRY(tc_layernorm_fwd(w.x, d->lnf_g, d->lnf_b, rep_last, (logits || !rep_last) ? w.h : nullptr, M, E, d->ln_eps,
-                                stream));
+    const float q_scale = bf ? 0.125f * 1.4426950408889634f : 0.125f;   // bf16: base-2 attention kernel
+    auto attention = [&]() {
+        return bf ? tc_attn_fwd_packed_q2(dt, w.qkv, 3 * E, attn_blocks, n_blocks, max_len, w.h, d->H, 64, attn_flops, stream)
+                  : tc_attn_fwd_packed(dt, w.qkv, 3 * E, attn_blocks, n_blocks, max_len, w.h, d->H, 64, attn_flops, stream);
+    };
+    // one "sequence" per row for the gather: species_row[m] is the species of row m's sequence
+    if (fold2) {
+        void *x_lo = w.x;
+        TC_TRY(tc_ln_rows_clear(w.row_acc, (int)w.rows_pad, stream));
+        TC_TRY(tc_embed_fwd_ln(tokens, species_row, d->tok_table, d->species_table, nullptr, nullptr, status, M, 1, E,
+                               d->vocab, d->n_species, d->pad_idx, w.xb, x_lo, w.ln_rows, d->ln_eps, stream));
+        for (int l = 0; l < d->num_layers; ++l) {
+            const tc_layer_weights &lw = d->layers[l];
+            TC_TRY(tc_layernorm_fwd_split(w.xb, x_lo, lw.ln1_g, lw.ln1_b, nullptr, w.h, M, E, d->ln_eps, stream));
+            TC_TRY(tc_gemm_qkv_packed(dt, w.h, E, lw.w_qkv, lw.b_qkv, w.qkv, 3 * E, M, 3 * E, E, q_scale, lw.rope_cos,
+                                      lw.rope_sin, pos, d->rope_table_len, 64, stream));
+            TC_TRY(attention());
+            TC_TRY(tc_gemm_residual_split(dt, w.h, E, lw.w_o, lw.b_o, w.xb, x_lo, w.row_acc, E, M, E, E, stream));
+            TC_TRY(tc_ln_rows_finalize(w.row_acc, w.ln_rows, M, E, d->ln_eps, stream));
+            TC_TRY(tc_gemm_ln(dt, TC_EPI_BIAS_GELU, w.xb, E, lw.w_fc1_ln, lw.c_fc1_ln, lw.s_fc1_ln, w.ln_rows, w.mid,
+                              w.ld_mid, M, F, E, 0.f, nullptr, nullptr, 0, 0, stream));
+            // no row sums here: the next layer's first LayerNorm is a kernel with its own statistics
+            TC_TRY(tc_gemm_residual_split(dt, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.xb, x_lo, nullptr, E, M, E, F, stream));
+        }
+        TC_TRY(tc_layernorm_fwd_split(w.xb, x_lo, d->lnf_g, d->lnf_b, rep_last, (logits || !rep_last) ? w.h : nullptr, M, E,
+                                      d->ln_eps, stream));
     } else {
-        float *dst = logits ? static_cast<float *>(w.h) : rep_last;      // embedding extraction writes the result directly
-        TC_TRY(tc_layernorm_fwd(w.x, d->lnf_g, d->lnf_b, dst, nullptr, M, E, d->ln_eps, stream));
-        if (rep_last && dst != rep_last) {
-            TC_TRY(tc_copy_f32(rep_last, static_cast<const float *>(w.h), (long)M * E, stream));
+        TC_TRY(tc_embed_fwd(tokens, species_row, d->tok_table, d->species_table, w.x, nullptr, status, M, 1, E, d->vocab,
+                            d->n_species, d->pad_idx, stream));
+        for (int l = 0; l < d->num_layers; ++l) {
+            const tc_layer_weights &lw = d->layers[l];
+            TC_TRY(ln(lw.ln1_g, lw.ln1_b, nullptr));
+            TC_TRY(tc_gemm_qkv_packed(dt, w.h, E, lw.w_qkv, lw.b_qkv, w.qkv, 3 * E, M, 3 * E, E, q_scale, lw.rope_cos,
+                                      lw.rope_sin, pos, d->rope_table_len, 64, stream));
+            TC_TRY(attention());
+            TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.h, E, lw.w_o, lw.b_o, w.x, w.x, E, M, E, E, 0.f, nullptr, nullptr, 0,
+                           0, stream));
+            TC_TRY(ln(lw.ln2_g, lw.ln2_b, nullptr));
+            TC_TRY(tc_gemm(dt, TC_EPI_BIAS_GELU, w.h, E, lw.w_fc1, lw.b_fc1, nullptr, w.mid, w.ld_mid, M, F, E, 0.f,
+                           nullptr, nullptr, 0, 0, stream));
+            TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.x, w.x, E, M, E, F, 0.f,
+                           nullptr, nullptr, 0, 0, stream));
+        }
+        if (bf) {
+            TC_TRY(tc_layernorm_fwd(w.x, d->lnf_g, d->lnf_b, rep_last, (logits || !rep_last) ? w.h : nullptr, M, E,
+                                    d->ln_eps, stream));
+        } else {
+            float *dst = logits ? static_cast<float *>(w.h) : rep_last;      // embedding extraction writes the result directly
+            TC_TRY(tc_layernorm_fwd(w.x, d->lnf_g, d->lnf_b, dst, nullptr, M, E, d->ln_eps, stream));
+            if (rep_last && dst != rep_last) {
+                TC_TRY(tc_copy_f32(rep_last, static_cast<const float *>(w.h), (long)M * E, stream));
+            }
         }
     }
     if (!logits) return TC_OK;              // embedding extraction needs no head

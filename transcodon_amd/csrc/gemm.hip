@@ -1850,17 +1850,17 @@ extern "C" int tc_gemm_residual_ln(int dtype, const void *A, int lda, const void
 extern "C" int tc_gemm_residual_split(int dtype, const void *A, int lda, const void *W, const float *bias, void *x_hi,
                                       void *x_lo, unsigned long long *row_acc, int ldo, int M, int N, int K,
                                       void *stream) {
-    TC_REQUIRE(x_hi && x_lo && row_acc && tc_aligned16(x_hi) && tc_aligned16(x_lo) && tc_aligned16(row_acc),
-               "tc_gemm_residual_split: needs both planes and the row accumulators, 16-byte aligned");
+    TC_REQUIRE(x_hi && x_lo && tc_aligned16(x_hi) && tc_aligned16(x_lo) && tc_aligned16(row_acc),
+               "tc_gemm_residual_split: needs both planes (and row accumulators, when given), 16-byte aligned");
     return gemm_impl(dtype, TC_EPI_BIAS_RESIDUAL, A, lda, W, bias, static_cast<const float *>(x_hi), nullptr, x_hi, x_hi,
                      ldo, M, N, K, 1, 0.f, nullptr, nullptr, 0, 0, stream, nullptr, nullptr, nullptr, row_acc, x_lo);
 }
 
-// 1 when a forward of M = B*T rows can run with its LayerNorms folded into the products: every
-// product of a layer (N = 3E, E, F) takes the alternating large-tile kernel and the rotary epilogue
-// its table-slice form.
-extern "C" int tc_ln_fold_supported(int dtype, int B, int T, int E, int F) {
-    if (dtype != TC_BF16 || B <= 0 || T <= 0 || !alt_schedule_enabled()) return 0;
+// 1 when the products of a layer that carry no rotary epilogue (out-proj, fc1, fc2) take the alternating
+// large-tile kernel for M rows, so that the second LayerNorm can be folded into fc1 and the residual stream
+// kept as bf16 planes.
+extern "C" int tc_ln_fold_rows_supported(int dtype, long M, int E, int F) {
+    if (dtype != TC_BF16 || M <= 0 || !alt_schedule_enabled()) return 0;
     if (g_num_cus == 0) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -1869,11 +1869,17 @@ extern "C" int tc_ln_fold_supported(int dtype, int B, int T, int E, int F) {
         g_num_cus = cus;
     }
     { const char *e = getenv("TC_GEMM_TILE"); if (e && atoi(e) == 128) return 0; }
-    const long M = (long)B * T;
-    if (E % 256 != 0 || F % 256 != 0 || T % 256 != 0) return 0;
+    if (E % 256 != 0 || F % 256 != 0) return 0;
     if (((M + 255) / 256) * (E / 256) < g_num_cus) return 0;
     if (M * (F + 64) * 2 >= (1L << 32)) return 0;
     return 1;
+}
+
+// 1 when a forward of M = B*T rows can run with all its LayerNorms folded into the products: as above, and
+// the q/k/v product's rotary epilogue takes its table-slice form (no sequence boundary inside a 256-row tile).
+extern "C" int tc_ln_fold_supported(int dtype, int B, int T, int E, int F) {
+    if (B <= 0 || T <= 0 || T % 256 != 0) return 0;
+    return tc_ln_fold_rows_supported(dtype, (long)B * T, E, F);
 }
 
 extern "C" int tc_gemm_train(int dtype, int epilogue, const void *A, int lda, const void *W, const float *bias,
