@@ -13,8 +13,9 @@
 // row-major V tile.  The per-query rescale is then a per-lane scalar.
 // Padded keys get -inf through 64-bit validity words (one per sequence and key tile).
 //
-// f32 kernel (exactness path): one 64-lane wave per 64 queries, one query per lane,
-// plain fmaf dot products over keys broadcast from LDS.
+// f32 kernels (exactness path): the same structure on mfma_f32_32x32x2_f32 (f32 operands, f32
+// accumulation) for sequences of up to 8192 keys; beyond that one 64-lane wave per 64 queries, one
+// query per lane, plain fmaf dot products over keys broadcast from LDS.
 #include "common.h"
 
 namespace {
@@ -497,6 +498,218 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// f32 on the matrix unit: mfma_f32_32x32x2_f32 multiplies f32 operands exactly and accumulates in f32 (the
+// rate of the f32 vector ALU, but 32 x 32 x 2 products per instruction instead of 64 per v_fma)
+// ------------------------------------------------------------------------------------------
+// Same structure as the bf16 kernel: a workgroup of 4 waves owns 128 queries of one (sequence, head), 32 per
+// wave; K/V tiles of 64 keys (256-byte rows) come in by direct-to-LDS loads, double buffered.  Per tile and wave
+//   S^T = K . Q^T : 2 key blocks x 32 MFMAs, step s multiplies head dimension s (lanes 0-31) and 32 + s (lanes
+//         32-63); the lane's 32 query values stay in registers, K values are 4-byte LDS reads from rows whose
+//         16-byte chunks are stored at chunk ^ (row & 7) (32 rows would otherwise share one bank);
+//   O^T += V^T . P^T : register r of a score block holds keys k(r) (lanes 0-31) and k(r) + 4 (lanes 32-63), which
+//         is the B operand as it stands; the A operand is V[that key][lane's column], a conflict-free row read.
+// The softmax is the bf16 kernel's (base 2, lazy running maximum), all in f32.
+namespace f32m {
+constexpr int kWavesF = 4;
+constexpr int ROW_BYTES = 256;
+constexpr int TILE_BYTES = 64 * ROW_BYTES;         // 64 keys
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;        // K + V
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;         // two stages: 64 KiB
+}  // namespace f32m
+
+__global__ __launch_bounds__(64 * f32m::kWavesF) void attn_f32_mfma_kernel(const AttnParams p) {
+    using namespace f32m;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int id = tc_xcd_remap(blockIdx.x, gridDim.x);
+    int qb, h, b, Tn;
+    long row_base;
+    if (p.blocks) {
+        const int4 blk = p.blocks[id / p.H];
+        h = id % p.H;
+        b = 0;
+        row_base = blk.x;
+        Tn = blk.y;
+        qb = blk.z;
+    } else {
+        qb = id % p.nqb;
+        const int bh = id / p.nqb;
+        h = bh % p.H;
+        b = bh / p.H;
+        Tn = p.T;
+        row_base = (long)b * p.T;
+    }
+    const int nw = (Tn + 63) >> 6;
+    const int ql = lane & 31, h2 = lane >> 5;
+    const int q0 = qb * (32 * kWavesF) + wid * 32;
+    const bool q_live = q0 < Tn;                   // wave-uniform
+
+    __shared__ uint64_t s_words[kMaxWords];
+    for (int i = threadIdx.x; i < nw && i < kMaxWords; i += 64 * kWavesF) s_words[i] = key_word(p, b, i, Tn, nw);
+    __syncthreads();
+    int nkt = nw;
+    while (nkt > 0 && s_words[nkt - 1] == 0ull) --nkt;
+
+    // Q: lane (query ql, half h2) holds head dimensions 32 h2 .. 32 h2 + 31
+    float qf[32];
+    {
+        int qr = q0 + ql;
+        qr = qr < Tn ? qr : Tn - 1;
+        const char *src = p.qkv + (row_base + qr) * p.ldq_bytes + (long)h * ROW_BYTES + h2 * 128;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(src + i * 16);
+            qf[4 * i] = v[0]; qf[4 * i + 1] = v[1]; qf[4 * i + 2] = v[2]; qf[4 * i + 3] = v[3];
+        }
+    }
+
+    // staging: a piece is 4 rows x 256 B (lane -> row lane >> 4, 16-byte chunk lane & 15); a wave moves 4 pieces
+    // of K and 4 of V per tile.  K chunks are swizzled on the source side: LDS position c holds chunk c ^ (row & 7).
+    const int srow = lane >> 4, spos = lane & 15;
+    unsigned k_col[4], v_col;
+    int s_row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wid * 4 + i) * 4 + srow;
+        s_row[i] = r;
+        k_col[i] = (unsigned)(p.E + h * 64) * 4u + (unsigned)((spos ^ (r & 7)) << 4);
+    }
+    v_col = (unsigned)(2 * p.E + h * 64) * 4u + (unsigned)(spos << 4);
+    const __amdgpu_buffer_rsrc_t rsrc_kv = tc_buffer_rsrc(p.qkv + row_base * p.ldq_bytes);
+    auto stage = [&](int buf, int kt) {
+        char *kb = smem + buf * STAGE_BYTES + wid * 4096;
+        char *vb = kb + TILE_BYTES;
+        const bool full = kt * 64 + 64 <= Tn;
+        const unsigned tile_off = full ? (unsigned)((long)kt * 64 * p.ldq_bytes) : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int key = s_row[i];
+            if (!full) {                           // rows past the sequence re-read its last row (their keys are masked)
+                key += kt * 64;
+                key = key < Tn ? key : Tn - 1;
+            }
+            const unsigned row_off = (unsigned)(key * p.ldq_bytes);
+            tc_blds16(rsrc_kv, row_off + k_col[i], tile_off, kb + i * 1024);
+            tc_blds16(rsrc_kv, row_off + v_col, tile_off, vb + i * 1024);
+        }
+    };
+
+    // LDS read offsets.  K: row ql (+ 32 per key block), head dimension s + 32 h2 -> chunk (s >> 2) + 8 h2, word s & 3
+    int k_off[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k_off[j] = ql * ROW_BYTES + (((j ^ (ql & 7)) + 8 * h2) << 4);
+    // V: key k(r) + 4 h2 (+ 32 per key block), column ql (+ 32 per column block)
+    const int v_off = TILE_BYTES + 4 * h2 * ROW_BYTES + 4 * ql;
+
+    f32x16 acc_o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    if (nkt > 0) stage(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                           // tile kt landed; everyone is done with the other stage
+        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+        if (!q_live) continue;
+        const char *sb = smem + (kt & 1) * STAGE_BYTES;
+
+        f32x16 acc_s[2];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const float kv = *reinterpret_cast<const float *>(sb + k_off[s >> 2] + kb * 32 * ROW_BYTES + 4 * (s & 3));
+                acc_s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qf[s], s == 0 ? zero16 : acc_s[kb], 0, 0, 0);
+            }
+
+        const uint64_t word = s_words[kt];
+        if (word != ~0ull) {
+            const uint64_t wsh = word >> (4 * h2);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const uint32_t wk = (uint32_t)(wsh >> (32 * kb));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int bit = (r & 3) + 8 * (r >> 2);
+                    acc_s[kb][r] = ((wk >> bit) & 1u) ? acc_s[kb][r] : -INFINITY;
+                }
+            }
+        }
+        float tm0 = fmaxf(acc_s[0][0], acc_s[0][1]), tm1 = fmaxf(acc_s[1][0], acc_s[1][1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) {
+            tm0 = fmaxf(fmaxf(tm0, acc_s[0][r]), acc_s[0][r + 1]);
+            tm1 = fmaxf(fmaxf(tm1, acc_s[1][r]), acc_s[1][r + 1]);
+        }
+        float tmax = fmaxf(tm0, tm1);
+        {
+            float a = tmax, b2 = tmax;             // maximum with lane ^ 32: the other 32 keys of the query
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b2));
+            tmax = fmaxf(a, b2) * kLog2e;
+        }
+        constexpr float kLazy = 8.0f;              // lazy running maximum, as in the bf16 kernel
+        const float m_new = (tmax > m_run + kLazy) ? tmax : m_run;
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        float lsum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(acc_s[kb][r], kLog2e, -m_use));
+                acc_s[kb][r] = e;
+                lsum += e;
+            }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+        }
+
+        // O^T[d][query] += V^T[d][key] P^T[key][query], one MFMA per score register and column block
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key_row = (r & 3) + 8 * (r >> 2) + 32 * kb;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const float vv = *reinterpret_cast<const float *>(sb + v_off + key_row * ROW_BYTES + db * 128);
+                    acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, acc_s[kb][r], acc_o[db], 0, 0, 0);
+                }
+            }
+    }
+
+    // normalise and store: lane (query ql, half h2) holds columns 32 db + 8 g + 4 h2 .. + 3 in registers 4 g .. 4 g + 3
+    float l_tot;
+    {
+        float a = l_run, b2 = l_run;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b2));
+        l_tot = a + b2;
+    }
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const int q = q0 + ql;
+    if (!q_live || q >= Tn) return;
+    if (p.lse && h2 == 0)
+        p.lse[((long)b * p.H + h) * p.T + q] = l_tot > 0.f ? (m_run + __log2f(l_tot)) * 0.69314718055994531f : INFINITY;
+    char *dst = p.out + (row_base + q) * p.ldo_bytes + (long)h * ROW_BYTES;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4 *>(dst + (32 * db + 8 * g + 4 * h2) * 4) =
+                f32x4{acc_o[db][4 * g] * inv, acc_o[db][4 * g + 1] * inv, acc_o[db][4 * g + 2] * inv, acc_o[db][4 * g + 3] * inv};
+}
+
+// ------------------------------------------------------------------------------------------
 // pre-softmax scores (slow path for callers that ask for attention maps)
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -533,6 +746,20 @@ static int attn_fwd_impl(int dtype, const void *qkv, int ldq, const uint64_t *ke
                          int B, int T, int H, int D, bool q2, void *stream);
 static int attn_fwd_packed_impl(int dtype, const void *qkv, int ldq, const int32_t *blocks, int n_blocks, int max_len,
                                 void *out, int H, int D, double flops, bool q2, void *stream);
+
+static int attn_f32_mfma_attr(const char *who) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_f32_mfma_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, f32m::LDS_BYTES);
+        if (e != hipSuccess) {
+            tc_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+            return TC_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    return TC_OK;
+}
 
 // The bf16 kernel's LDS request, once per variant
 template <bool Q2>
@@ -597,7 +824,15 @@ static int attn_fwd_impl(int dtype, const void *qkv, int ldq, const uint64_t *ke
         TC_REQUIRE(p.nw <= kMaxWords, "tc_attn_fwd: T=%d exceeds the bf16 kernel's %d keys", T, kMaxWords * 64);
         if (q2) TC_LAUNCH(attn_bf16_kernel<true>, dim3((unsigned)grid), dim3(64 * kWaves), ATTN_LDS_BYTES, s, p);
         else TC_LAUNCH(attn_bf16_kernel<false>, dim3((unsigned)grid), dim3(64 * kWaves), ATTN_LDS_BYTES, s, p);
+    } else if (p.nw <= kMaxWords) {
+        const int rc = attn_f32_mfma_attr("tc_attn_fwd");
+        if (rc != TC_OK) return rc;
+        p.nqb = (T + 32 * f32m::kWavesF - 1) / (32 * f32m::kWavesF);
+        const long grid = (long)p.nqb * H * B;
+        TC_REQUIRE(grid < (1L << 31), "tc_attn_fwd: grid too large");
+        TC_LAUNCH(attn_f32_mfma_kernel, dim3((unsigned)grid), dim3(64 * f32m::kWavesF), f32m::LDS_BYTES, s, p);
     } else {
+        // beyond the validity-word table of the MFMA kernel: one query per lane, any length
         p.nqb = (T + 63) / 64;
         const long grid = (long)p.nqb * H * B;
         TC_REQUIRE(grid < (1L << 31), "tc_attn_fwd: grid too large");
@@ -631,8 +866,8 @@ static int attn_fwd_packed_impl(int dtype, const void *qkv, int ldq, const int32
     TC_REQUIRE(ldq >= 3 * E && (ldq * esz) % 16 == 0, "tc_attn_fwd_packed: ldq=%d too small or misaligned", ldq);
     TC_REQUIRE(tc_aligned16(qkv) && tc_aligned16(out) && tc_aligned16(blocks),
                "tc_attn_fwd_packed: operands must be 16-byte aligned");
-    TC_REQUIRE(dtype != TC_BF16 || (max_len + 63) / 64 <= kMaxWords,
-               "tc_attn_fwd_packed: a sequence of %d tokens exceeds the bf16 kernel's %d keys", max_len, kMaxWords * 64);
+    TC_REQUIRE((max_len + 63) / 64 <= kMaxWords,
+               "tc_attn_fwd_packed: a sequence of %d tokens exceeds the kernels' %d keys", max_len, kMaxWords * 64);
     AttnParams p{};
     p.qkv = static_cast<const char *>(qkv);
     p.out = static_cast<char *>(out);
@@ -650,14 +885,16 @@ static int attn_fwd_packed_impl(int dtype, const void *qkv, int ldq, const int32
         if (q2) TC_LAUNCH(attn_bf16_kernel<true>, dim3((unsigned)grid), dim3(64 * kWaves), ATTN_LDS_BYTES, s, p);
         else TC_LAUNCH(attn_bf16_kernel<false>, dim3((unsigned)grid), dim3(64 * kWaves), ATTN_LDS_BYTES, s, p);
     } else {
-        TC_LAUNCH(attn_f32_kernel, dim3((unsigned)grid), dim3(64), 0, s, p);
+        const int rc = attn_f32_mfma_attr("tc_attn_fwd_packed");
+        if (rc != TC_OK) return rc;
+        TC_LAUNCH(attn_f32_mfma_kernel, dim3((unsigned)grid), dim3(64 * f32m::kWavesF), f32m::LDS_BYTES, s, p);
     }
     TC_CHECK_LAUNCH("tc_attn_fwd_packed");
     return TC_OK;
 }
 
 // rows per query block of tc_attn_fwd_packed's block list for an element type
-extern "C" int tc_attn_packed_block_rows(int dtype) { return dtype == TC_BF16 ? 32 * kWaves : 64; }
+extern "C" int tc_attn_packed_block_rows(int dtype) { return dtype == TC_BF16 ? 32 * kWaves : 32 * f32m::kWavesF; }
 
 extern "C" int tc_attn_scores(int dtype, const void *qkv, int ldq, const uint8_t *pad_flags,
                               float *scores, int B, int T, int H, int D, void *stream) {
