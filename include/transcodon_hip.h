@@ -391,6 +391,10 @@ int tc_ln_rows_finalize(unsigned long long *row_acc, float *ln_rows, int M, int 
  * representations with.  On this stack the memset and copy nodes of a captured graph are not ordered against the
  * graph's previous launch, kernel nodes are. */
 int tc_copy_f32(float *dst, const float *src, long n, void *stream);
+/* x[m,n] += bias[n] + sum_s slabs[s][m][n] (f32; slabs = S split-K partial products of tc_gemm_train's plain
+ * epilogue, M*N elements apart): the bias + residual epilogue (modules.py:96-97,102-104) of a product too small
+ * to fill the chip with whole-K tiles.  tc_encoder_forward uses it for the f32 out-proj and fc2 of short batches. */
+int tc_splitk_bias_residual(const float *slabs, int S, const float *bias, float *x, int M, int N, void *stream);
 /* row_acc [M,2] to zero, as a kernel launch (what a forward starts with; graph-capture safe) */
 int tc_ln_rows_clear(unsigned long long *row_acc, int M, void *stream);
 int tc_gemm_ln(int dtype, int epilogue, const void *A, int lda, const void *Wf, const float *c, const float *s,

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "tc_ln_rows_finalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "tc_ln_rows_clear": (C.c_int, [vp, C.c_int, vp]),
     "tc_copy_f32": (C.c_int, [vp, vp, C.c_long, vp]),
+    "tc_splitk_bias_residual": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     "tc_ln_fold_weights": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "tc_gemm_ln": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_float, vp, vp, C.c_int, C.c_int, vp]),

@@ -79,6 +79,17 @@ extern "C" size_t tc_workspace_bytes(const tc_encoder_desc *desc, int B, int T) 
         if (rc__ != TC_OK) return rc__; \
     } while (0)
 
+// x += A W^T + b on the f32 residual stream (modules.py:96-97,102-104).  A short f32 batch has only a few dozen
+// 128 x 128 tiles of N = E columns: its k range is then cut in three, the parts land in the q/k/v buffer (free
+// once attention has run: 3 x [M, E] is exactly its size) and one small kernel adds them, the bias and x.
+static int residual_product_f32x(int dt, const Workspace &w, const void *A, int lda, const void *W, const float *bias, int M,
+                                 int E, int K, void *stream) {
+    if (dt != TC_F32 || M > 2048)
+        return tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, A, lda, W, bias, w.x, w.x, E, M, E, K, 0.f, nullptr, nullptr, 0, 0, stream);
+    TC_TRY(tc_gemm_train(dt, TC_EPI_PLAIN_F32, A, lda, W, nullptr, nullptr, w.qkv, nullptr, E, M, E, K, 3, stream));
+    return tc_splitk_bias_residual(static_cast<const float *>(w.qkv), 3, bias, w.x, M, E, stream);
+}
+
 extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *tokens,
                                   const int32_t *species, int B, int T, float *logits,
                                   float *struct_logits, float *rep_last, int n_rep,
@@ -111,6 +122,9 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
     auto ln = [&](const float *g, const float *b, float *extra_f32) {
         return tc_layernorm_fwd(w.x, g, b, bf ? extra_f32 : static_cast<float *>(w.h),
                                 bf ? w.h : nullptr, M, E, d->ln_eps, stream);
+    };
+    auto residual_product = [&](const void *A, int lda, const void *W, const float *bias, int K) {
+        return residual_product_f32x(dt, w, A, lda, W, bias, M, E, K, stream);
     };
     void *x_lo = w.x;          // folded forward: the residual stream is the plane pair (w.xb, x_lo), no f32 copy exists
     bool fold = false;
@@ -173,13 +187,11 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
         TC_TRY(tc_gemm(dt, TC_EPI_QKV_ROPE, w.h, E, lw.w_qkv, lw.b_qkv, nullptr, w.qkv, 3 * E, M, 3 * E, E,
                        q_scale, lw.rope_cos, lw.rope_sin, T, 64, stream));
         TC_TRY(attn());
-        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.h, E, lw.w_o, lw.b_o, w.x, w.x, E, M, E, E, 0.f, nullptr,
-                       nullptr, 0, 0, stream));
+        TC_TRY(residual_product(w.h, E, lw.w_o, lw.b_o, E));
         TC_TRY(ln(lw.ln2_g, lw.ln2_b, nullptr));
         TC_TRY(tc_gemm(dt, TC_EPI_BIAS_GELU, w.h, E, lw.w_fc1, lw.b_fc1, nullptr, w.mid, w.ld_mid, M, F, E, 0.f,
                        nullptr, nullptr, 0, 0, stream));
-        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.x, w.x, E, M, E, F, 0.f,
-                       nullptr, nullptr, 0, 0, stream));
+        TC_TRY(residual_product(w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, F));
         if (l + 1 < d->num_layers) TC_TRY(save_rep(l + 1));
     }
 
@@ -300,13 +312,11 @@ extern "C" int tc_encoder_forward_packed(const tc_encoder_desc *d, const int32_t
             TC_TRY(tc_gemm_qkv_packed(dt, w.h, E, lw.w_qkv, lw.b_qkv, w.qkv, 3 * E, M, 3 * E, E, q_scale, lw.rope_cos,
                                       lw.rope_sin, pos, d->rope_table_len, 64, stream));
             TC_TRY(attention());
-            TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.h, E, lw.w_o, lw.b_o, w.x, w.x, E, M, E, E, 0.f, nullptr, nullptr, 0,
-                           0, stream));
+            TC_TRY(residual_product_f32x(dt, w, w.h, E, lw.w_o, lw.b_o, M, E, E, stream));
             TC_TRY(ln(lw.ln2_g, lw.ln2_b, nullptr));
             TC_TRY(tc_gemm(dt, TC_EPI_BIAS_GELU, w.h, E, lw.w_fc1, lw.b_fc1, nullptr, w.mid, w.ld_mid, M, F, E, 0.f,
                            nullptr, nullptr, 0, 0, stream));
-            TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.x, w.x, E, M, E, F, 0.f,
-                           nullptr, nullptr, 0, 0, stream));
+            TC_TRY(residual_product_f32x(dt, w, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, M, E, F, stream));
         }
         if (bf) {
             TC_TRY(tc_layernorm_fwd(w.x, d->lnf_g, d->lnf_b, rep_last, (logits || !rep_last) ? w.h : nullptr, M, E,

@@ -104,6 +104,20 @@ __global__ __launch_bounds__(256) void ln_rows_clear_kernel(unsigned long long *
         *reinterpret_cast<u32x4 *>(row_acc + 2 * i) = u32x4{0u, 0u, 0u, 0u};
 }
 
+// x[m,n] += bias[n] + sum over S split-K partial products [S][M][N]: the residual epilogue of a small f32 product
+// whose k range was cut into S parts to fill the chip (the parts are added in index order: deterministic)
+__global__ __launch_bounds__(256) void splitk_bias_residual_kernel(const float *__restrict__ slabs, int S, long slab_elems,
+                                                                   const float *__restrict__ bias, float *__restrict__ x,
+                                                                   long n4, int N) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(slabs + 4 * i);
+        for (int sl = 1; sl < S; ++sl) acc += *reinterpret_cast<const f32x4 *>(slabs + sl * slab_elems + 4 * i);
+        const int n = (int)((4 * i) % N);
+        acc += *reinterpret_cast<const f32x4 *>(bias + n);
+        *reinterpret_cast<f32x4 *>(x + 4 * i) = *reinterpret_cast<const f32x4 *>(x + 4 * i) + acc;
+    }
+}
+
 // Device-to-device copy of f32 data as a kernel (for the same reason: copy nodes of a captured graph)
 __global__ __launch_bounds__(256) void copy_f32_kernel(const float *__restrict__ src, float *__restrict__ dst, long n4) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
@@ -682,6 +696,17 @@ extern "C" int tc_ln_rows_finalize(unsigned long long *row_acc, float *ln_rows, 
     TcProfScope prof(TC_PROF_LN_ROWS, s, (double)M * 40.0);        // 16 B read, 16 B cleared, 8 B written per row
     TC_LAUNCH(ln_rows_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, row_acc, ln_rows, M, E, eps);
     TC_CHECK_LAUNCH("tc_ln_rows_finalize");
+    return TC_OK;
+}
+
+extern "C" int tc_splitk_bias_residual(const float *slabs, int S, const float *bias, float *x, int M, int N, void *stream) {
+    TC_REQUIRE(slabs && bias && x && S >= 1 && M > 0 && N > 0 && N % 4 == 0, "tc_splitk_bias_residual: bad operand");
+    TC_REQUIRE(tc_aligned16(slabs) && tc_aligned16(bias) && tc_aligned16(x), "tc_splitk_bias_residual: operands must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long n4 = (long)M * N / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536);
+    TC_LAUNCH(splitk_bias_residual_kernel, dim3(grid), dim3(256), 0, s, slabs, S, (long)M * N, bias, x, n4, N);
+    TC_CHECK_LAUNCH("tc_splitk_bias_residual");
     return TC_OK;
 }
 
