@@ -66,6 +66,7 @@ struct GemmParams {
     float q_scale;
     int gm;          // large-tile kernel: row panels per ordering group (1 = n-fastest)
     int gn;          // large-tile kernel: column panels per ordering group (tiles_n = no grouping)
+    int cg_w0;       // alternating kernel: column panels of the first of two column groups (0 = one group)
 #ifdef TC_GEMM_STAMPS
     unsigned long long *stamps;   // per workgroup: wait, issue, math, epilogue cycles (wave 0)
     int nostore;                  // experiment: the large-tile epilogue skips its final stores
@@ -1149,16 +1150,35 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     const int count = q + (cls < r ? 1 : 0);
     const int my_count = count > j ? (count - j + per_class - 1) / per_class : 0;
     if (my_count == 0) return;
-    // Tile order: column panel fastest.  A workgroup's tiles are per_class apart, so (row panel,
-    // column panel) advances by a fixed step with one carry: no division after this point (each
-    // one is a 100-clock dependent chain, and six cursors a tile would pay it).
-    const int step_m = per_class / p.tiles_n, step_n = per_class - step_m * p.tiles_n;
+    // Tile order: column panel fastest inside a column group, all row panels of the first group (cg_w0 column
+    // panels), then those of the second (the rest): with half the columns the weight panels an XCD works on
+    // at one time (cg_w0 x 256 x K) stay in its L2 while the row panels stream by, instead of the whole
+    // weight matrix cycling through it once per 32 tiles.  cg_w0 = 0: one group of all columns.
+    // A workgroup's tiles are per_class apart, so (row panel, column panel) advances by a fixed step with one
+    // carry: no division after this point except where a cursor crosses into the second group (each division
+    // is a 100-clock dependent chain, and six cursors a tile would pay it).
+    const int w0 = p.cg_w0 > 0 && p.cg_w0 < p.tiles_n ? p.cg_w0 : p.tiles_n;
+    const int w1 = p.tiles_n - w0, w1s = w1 > 0 ? w1 : 1;
+    const int base1 = p.tiles_m * w0;                       // linear index of the second group's first tile
+    const int sm0 = per_class / w0, sn0 = per_class - sm0 * w0;
+    const int sm1 = per_class / w1s, sn1 = per_class - sm1 * w1s;
+    auto locate = [&](int idx, int &tm, int &tn) {
+        if (idx < base1) { tm = idx / w0; tn = idx - tm * w0; }
+        else { const int l = idx - base1; tm = l / w1s; tn = w0 + l - tm * w1s; }
+    };
     const int tile0 = first + j;
-    const int tm0 = tile0 / p.tiles_n, tn0 = tile0 - tm0 * p.tiles_n;
-    auto advance = [&](int &tm, int &tn) {
-        tn += step_n;
-        tm += step_m;
-        if (tn >= p.tiles_n) { tn -= p.tiles_n; ++tm; }
+    int tm0, tn0;
+    locate(tile0, tm0, tn0);
+    auto advance = [&](int &tm, int &tn, int &idx) {
+        const int nidx = idx + per_class;
+        if (idx < base1) {
+            if (nidx >= base1) locate(nidx, tm, tn);
+            else { tn += sn0; tm += sm0; if (tn >= w0) { tn -= w0; ++tm; } }
+        } else {
+            tn += sn1; tm += sm1;
+            if (tn >= p.tiles_n) { tn -= w1s; ++tm; }
+        }
+        idx = nidx;
     };
 
     // ---- staging: a half-tile is 16 pieces of 8 rows x 128 B; this wave moves pieces 2 wid, 2 wid + 1
@@ -1180,6 +1200,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         return (unsigned)(tn * BN + h * 128 + (wid * 2 + i) * 8 + srow) * (unsigned)p.ldw_bytes + chunk * 16;
     };
     int c1m = tm0, c1n = tn0, c2m = tm0, c2n = tn0;      // tiles of the two staging cursors
+    int c1i = tile0, c2i = tile0, ti = tile0;            // ... and their linear indices (and the math cursor's)
     auto set_c1 = [&]() { a1_src[0] = a_src_of(c1m, 1, 0); a1_src[1] = a_src_of(c1m, 1, 1); };
     auto set_c2 = [&]() {
         const int tm = c2m, tn = c2n;
@@ -1275,7 +1296,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     stage_half(DBUF_BYTES + SLOT_B1, p.W, b1_src, 128);
     int c1_tile = 0, c1_k = 1;                   // next A1 to stage
     int c2_tile = 0, c2_k = 2;                   // next B0 A0 B1 to stage
-    if (c2_k == p.nk) { c2_k = 0; c2_tile = 1; if (c2_tile < my_count) { advance(c2m, c2n); set_c2(); } }
+    if (c2_k == p.nk) { c2_k = 0; c2_tile = 1; if (c2_tile < my_count) { advance(c2m, c2n, c2i); set_c2(); } }
     if constexpr (kGeluTable) {
 #pragma unroll
         for (int e = threadIdx.x; e < kPhiEntries; e += 512)
@@ -1434,7 +1455,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             if (kPiece && kt == 1) stage_epilogue_inputs(tm, tn);
             if (c1_tile < my_count) {
                 stage_half(nxt + SLOT_A1, p.A, a1_src, (unsigned)c1_k * 128u);
-                if (++c1_k == p.nk) { c1_k = 0; if (++c1_tile < my_count) { advance(c1m, c1n); set_c1(); } }
+                if (++c1_k == p.nk) { c1_k = 0; if (++c1_tile < my_count) { advance(c1m, c1n, c1i); set_c1(); } }
             }
             if constexpr (kQuarters) {
                 if (after) finish_quarter(ptm, ptn, I0{}, I0{});
@@ -1496,7 +1517,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             }
             if (more) {
                 if (!(kQuarters && after)) stage_half(cur + SLOT_B1, p.W, b1_src, koff2);
-                if (++c2_k == p.nk) { c2_k = 0; if (++c2_tile < my_count) { advance(c2m, c2n); set_c2(); } }
+                if (++c2_k == p.nk) { c2_k = 0; if (++c2_tile < my_count) { advance(c2m, c2n, c2i); set_c2(); } }
                 if (after && prev_full) {
                     if constexpr (kTileStores == 32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
@@ -1543,7 +1564,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         }
         ptm = tm;
         ptn = tn;
-        advance(tm, tn);
+        advance(tm, tn, ti);
     }
 #ifdef TC_GEMM_STAMPS
     if (p.stamps && (threadIdx.x == 0 || threadIdx.x == 256)) {
@@ -1621,6 +1642,13 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
             if (force == -2) { const char *e = getenv("TC_GEMM_GN"); force = e ? atoi(e) : -1; }
             p.gn = force > 0 && force < p.tiles_n ? force : p.tiles_n;
             if (p.gm > 1) p.gn = p.tiles_n;
+        }
+        {
+            // alternating kernel: two column groups from 10 column panels on (fc1: its 4.7 MB of weights do not fit an
+            // XCD's L2; q/k/v with 9 panels and 3.5 MB ran 5-7 % slower grouped); TC_GEMM_CG=0 turns it off
+            static int cg = -2;
+            if (cg == -2) { const char *e = getenv("TC_GEMM_CG"); cg = e ? atoi(e) : -1; }
+            p.cg_w0 = cg == 0 ? 0 : (cg > 0 ? cg : (p.tiles_n >= 10 ? (p.tiles_n + 1) / 2 : 0));
         }
 #ifdef TC_GEMM_STAMPS
         p.stamps = g_stamps;
