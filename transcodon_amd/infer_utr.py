@@ -299,6 +299,19 @@ def _optimize(model, items, dev, max_batch_tokens, packed):
     import numpy as np
     order = sorted(range(len(items)), key=lambda k: len(items[k][1]))
     out: List[Optional[str]] = [None] * len(items)
+
+    def finish(host_buf, done, chunk, offs):
+        """Host side of one batch: wait for its bases, check the back-translation, cut the strings."""
+        done.synchronize()
+        host = host_buf.numpy()
+        wrong = back_translation_mismatch(host, np.frombuffer("".join(c[3] for c in chunk).encode("ascii"), np.uint8), offs)
+        if wrong >= 0:
+            raise RuntimeError(f"prediction for sequence {chunk[wrong][0]} does not translate back to its protein")
+        flat_s = host.tobytes().decode("ascii")
+        for r, c in enumerate(chunk):
+            out[c[0]] = flat_s[3 * offs[r]:3 * offs[r + 1]]
+
+    pending = None
     pos = 0
     while pos < len(order):
         width, ntok = 0, 0
@@ -338,11 +351,15 @@ def _optimize(model, items, dev, max_batch_tokens, packed):
             torch.frombuffer(bytearray(aa_all), dtype=torch.uint8).to(dev),
             torch.tensor(offs, dtype=torch.int32, device=dev),
             torch.tensor(row0, dtype=torch.int32, device=dev))
-        host = bases.cpu().numpy()
-        wrong = back_translation_mismatch(host, np.frombuffer("".join(c[3] for c in chunk).encode("ascii"), np.uint8), offs)
-        if wrong >= 0:
-            raise RuntimeError(f"prediction for sequence {chunk[wrong][0]} does not translate back to its protein")
-        flat_s = host.tobytes().decode("ascii")
-        for r, c in enumerate(chunk):
-            out[c[0]] = flat_s[3 * offs[r]:3 * offs[r + 1]]
+        # The decoded bases travel to a pinned host buffer asynchronously; the host part of THIS batch (check,
+        # strings) runs after the NEXT batch's kernels have been queued, so the GPU never waits for it.
+        host_buf = torch.empty(bases.numel(), dtype=torch.uint8).pin_memory()
+        host_buf.copy_(bases, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        if pending is not None:
+            finish(*pending)
+        pending = (host_buf, done, chunk, offs)
+    if pending is not None:
+        finish(*pending)
     return out
