@@ -351,8 +351,9 @@ def test_attention_online_softmax_rescale(q2):
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("jump", [30.0, 120.0])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, "bf16_q2"])
-def test_attention_lazy_running_maximum_staircase(dtype):
+def test_attention_lazy_running_maximum_staircase(dtype, jump):
     """The bf16 kernel moves its softmax offset only when a key tile's maximum exceeds it by more
     than 2^8; scores that climb tile after tile (steps below and above that threshold, in both
     directions) must still give the exact softmax.  Checked against float64 on every query."""
@@ -364,7 +365,9 @@ def test_attention_lazy_running_maximum_staircase(dtype):
     q[:, 0] = 1.0
     # per 64-key tile a shift of the whole tile's scores, in natural-log units: +3.5 and +7 stay below the
     # lazy threshold (8 in log2 units = 5.5 nats) cumulatively crossing it, -20 falls far below, +30 jumps
-    steps = torch.tensor([0.0, 3.5, 7.0, 4.0, -20.0, 30.0, 33.0, 12.0])
+    # jump = 120 nats (173 in log2 units) overflows an exponential taken against the first tile's offset: the
+    # base-2 kernel's loop without tile maxima must notice and repeat itself with them
+    steps = torch.tensor([0.0, 3.5, 7.0, 4.0, -20.0, jump, jump + 3.0, 12.0])
     k[:, 0] = steps.repeat_interleave(64).repeat(B)
     qkv = torch.cat([q, k, v], 1)
     if dtype == "bf16_q2":

@@ -17,6 +17,7 @@
 // accumulation) for sequences of up to 8192 keys; beyond that one 64-lane wave per 64 queries, one
 // query per lane, plain fmaf dot products over keys broadcast from LDS.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -106,7 +107,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_bf16_kernel(const AttnPar
     // The key-validity words of this batch row go to LDS once: a global load consumed inside the
     // key loop would make the compiler wait for everything in flight, the K/V prefetch included.
     __shared__ uint64_t s_words[kMaxWords];
+    __shared__ int s_danger;                       // Q2: some wave saw an exponential out of range
     for (int i = threadIdx.x; i < nw && i < kMaxWords; i += 64 * kWaves) s_words[i] = key_word(p, b, i, Tn, nw);
+    if (threadIdx.x == 0) s_danger = 0;
     __syncthreads();
     auto tile_word = [&](int kt) { return s_words[kt]; };       // the host checks nw <= kMaxWords
 
@@ -198,6 +201,12 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_bf16_kernel(const AttnPar
         }
     };
 
+    // Q2 runs the key loop without tile maxima (see below) and watches for an exponential out of range; in that
+    // case, which needs a score 2^40 above a query's first tile, the whole workgroup runs the loop a second time
+    // with the maxima (the waves share the staged tiles and their barriers, so they repeat together).
+    bool danger = false;
+    auto key_loop = [&](auto with_max_c) {
+    constexpr bool with_max = decltype(with_max_c)::value;
     if (nkt > 0) stage(0, 0);
     if (kStages == 3 && nkt > 1) stage(1, 1);
     int buf = 0, buf_next = kStages - 1;           // ring slots of tile kt and of the tile staged at kt
@@ -252,27 +261,34 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_bf16_kernel(const AttnPar
             }
         }
 #ifndef TC_ABL_NOSOFTMAX
-        // two chains of three-input maxima (v_max3_f32): 18 instructions instead of 25
-        float tm0 = fmaxf(acc_s[0][0], acc_s[0][1]), tm1 = fmaxf(acc_s[1][0], acc_s[1][1]);
+        // maximum of the tile's scores over the query's 64 keys (this lane's 32 and lane ^ 32's)
+        auto tile_max = [&]() {
+            // two chains of three-input maxima (v_max3_f32): 18 instructions instead of 25
+            float tm0 = fmaxf(acc_s[0][0], acc_s[0][1]), tm1 = fmaxf(acc_s[1][0], acc_s[1][1]);
 #pragma unroll
-        for (int r = 2; r < 16; r += 2) {
-            tm0 = fmaxf(fmaxf(tm0, acc_s[0][r]), acc_s[0][r + 1]);
-            tm1 = fmaxf(fmaxf(tm1, acc_s[1][r]), acc_s[1][r + 1]);
-        }
-        float tmax = fmaxf(tm0, tm1);
-        {   // maximum with lane ^ 32 (the other 32 keys of the query) in the vector ALU: no LDS round trip in
-            // the softmax's dependent chain.  The swap leaves x[lane & 31] in a and x[32 + (lane & 31)] in b.
-            float a = tmax, b2 = tmax;
+            for (int r = 2; r < 16; r += 2) {
+                tm0 = fmaxf(fmaxf(tm0, acc_s[0][r]), acc_s[0][r + 1]);
+                tm1 = fmaxf(fmaxf(tm1, acc_s[1][r]), acc_s[1][r + 1]);
+            }
+            // the exchange with lane ^ 32 stays in the vector ALU: no LDS round trip in the softmax's dependent
+            // chain.  The swap leaves x[lane & 31] in a and x[32 + (lane & 31)] in b.
+            float a = fmaxf(tm0, tm1), b2 = a;
             asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b2));
-            tmax = fmaxf(a, b2);
-        }
+            return fmaxf(a, b2);
+        };
         // Lazy running maximum: the offset only moves when a tile's maximum exceeds it by more than
         // kLazy (log2 units), so P stays below 2^kLazy and the rescale of O (32 multiplies per lane)
         // is skipped for nearly every tile.  Exact up to rounding: any per-query offset cancels in the
         // final normalisation, which is done in fp32.
         constexpr float kLazy = 8.0f;
         if constexpr (Q2) {
-            // the scores already carry minus the offset: tmax is relative to it (absolute before the first valid key)
+            // The scores already carry minus the offset, so the exponentials can be taken as they stand: no maximum
+            // is needed once a query has its offset (every tile after its first valid key).  bf16 and f32 keep
+            // their relative precision whatever the size of P, and what an offset too low by up to 2^40 loses of
+            // earlier tiles is below f32 resolution; beyond that (`danger`) the loop is repeated with the maxima.
+            if (with_max || __builtin_amdgcn_ballot_w64(m_run == -INFINITY) != 0ull) {
+            // tmax is relative to the offset (absolute before the first valid key)
+            const float tmax = tile_max();
             const bool first = m_run == -INFINITY;
             const bool move = first ? tmax != -INFINITY : tmax > kLazy;
             if (__builtin_amdgcn_ballot_w64(move) != 0ull) {             // rare: first tile, or a maximum 2^kLazy above the offset
@@ -292,6 +308,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_bf16_kernel(const AttnPar
 #pragma unroll
                 for (int r = 0; r < 16; ++r) negm16[r] = nm;
             }
+            }
             // P is packed to bf16 pairs at once (the form P.V multiplies) and the row sum is taken over those
             // rounded values: one dot-product instruction per pair instead of two adds, and numerator and
             // denominator of the softmax see the same P
@@ -307,9 +324,11 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_bf16_kernel(const AttnPar
                     if (kb == 0) lsum0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w), ones, lsum0, false);
                     else lsum1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w), ones, lsum1, false);
                 }
-            l_run += lsum0 + lsum1;
+            const float ls = lsum0 + lsum1;
+            l_run += ls;
+            danger |= !(ls < 1099511627776.0f);                         // 2^40, or a NaN
         } else {
-            tmax *= kLog2e;
+            const float tmax = tile_max() * kLog2e;
             const float m_new = (tmax > m_run + kLazy) ? tmax : m_run;     // m_run = -inf: the first valid tile sets it
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
@@ -369,6 +388,29 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_bf16_kernel(const AttnPar
                         __builtin_shufflevector(lo[db], hi[db], 0, 1, 2, 3, 4, 5, 6, 7), pf, acc_o[db], 0, 0, 0);
             }
     }
+    };
+    bool synced = false;                           // every wave is known to be done with the K/V stages
+    if constexpr (Q2) {
+        key_loop(std::false_type{});
+        if (__builtin_amdgcn_ballot_w64(danger) != 0ull && lane == 0) s_danger = 1;
+        __syncthreads();
+        synced = true;
+        if (s_danger != 0) {
+            synced = false;
+            // out of range somewhere in the workgroup: start again, this time with the tile maxima
+            m_run = -INFINITY;
+            l_run = 0.f;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm16[r] = 0.f;
+            key_loop(std::true_type{});
+        }
+    } else {
+        key_loop(std::true_type{});
+    }
 
     // ---- epilogue: normalise, stage through the wave's LDS rows, store 16 B per lane ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -376,7 +418,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_bf16_kernel(const AttnPar
     if (p.lse && h2 == 0 && q0 + ql < Tn)
         p.lse[((long)b * p.H + h) * p.T + q0 + ql] =
             l_tot > 0.f ? (m_run + __log2f(l_tot)) * 0.69314718055994531f : INFINITY;
-    __syncthreads();                       // every wave is done with the K/V stages
+    if (!synced) __syncthreads();          // every wave is done with the K/V stages
     char *ost = smem + wid * OST_WAVE_BYTES;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
