@@ -322,8 +322,8 @@ def bench_varlen(args, world, rank, dev, dist_on, rccl_ranks=1):
                        "batches_per_step_rank0": len(prepared), "parallelism": f"sequence-sharded x{world}",
                        "rccl_ranks": rccl_ranks, "backend": args.backend if world > 1 else None, "seqs_per_s": round(n_total * args.steps / elapsed, 1),
                        "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3),
-                       "layernorm": "second LayerNorm of every layer folded into fc1, residual stream as bf16 hi/lo planes; "
-                                    "first LayerNorm and the final one are kernels (packed q/k/v gathers rotary factors per row)"},
+                       "layernorm": "both LayerNorms of every layer folded into the q/k/v and fc1 products (q/k/v over row panels of "
+                                    "<= 256 rows per sequence), residual stream as bf16 hi/lo planes; the final one is a kernel"},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel / gemm256_kernel (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n,

@@ -487,11 +487,23 @@ int tc_encoder_forward(const tc_encoder_desc *desc, const int32_t *tokens, const
  *                      [n_seq+1] used to validate lengths against the rope table and the block list.
  *                      logits [M,vocab] or NULL (then the heads are skipped: embedding extraction);
  *                      struct_logits [M,n_struct] or NULL; rep_last [M,E] or NULL.
+ *                      row_panels (or NULL): device int32 [n_panels,4], every sequence cut into pieces of at
+ *                      most 256 rows {first row, end row, position of the first row, 0}, n_panels =
+ *                      sum ceil(T_i / 256); with it a large bf16 batch runs the q/k/v product in its folded
+ *                      form as well (tc_gemm_ln_qkv_panels) and no LayerNorm kernel inside the layers.
  *                      Workspace: tc_workspace_bytes(desc, 1, M).
+ * tc_gemm_ln_qkv_panels  tc_gemm_ln with the q/k/v epilogue for a packed batch: row panel i of the launch is
+ *                      rows [panels[4i], panels[4i+1]) of A and out, all of one sequence, rotary positions
+ *                      panels[4i+2] + r (tables of table_rows >= 96 rows).  Rows and positions in the list
+ *                      are the caller's contract (not checked on the device).
  */
 int tc_gemm_qkv_packed(int dtype, const void *A, int lda, const void *W, const float *bias, void *out, int ldo,
                        int M, int N, int K, float q_scale, const float *rope_cos, const float *rope_sin,
                        const int32_t *pos, int table_rows, int head_dim, void *stream);
+int tc_gemm_ln_qkv_panels(int dtype, const void *A, int lda, const void *Wf, const float *c, const float *s,
+                          const float *rows, void *out, int ldo, int M, int N, int K, float q_scale,
+                          const float *rope_cos, const float *rope_sin, int table_rows, int head_dim,
+                          const int32_t *panels, int n_panels, void *stream);
 int tc_attn_packed_block_rows(int dtype);
 int tc_attn_fwd_packed(int dtype, const void *qkv, int ldq, const int32_t *blocks, int n_blocks, int max_len,
                        void *out, int H, int D, double flops, void *stream);
@@ -502,6 +514,7 @@ int tc_mean_pool_packed(const float *rep, const int32_t *row_start, const int32_
                         int total_rows, int E, void *stream);
 int tc_encoder_forward_packed(const tc_encoder_desc *desc, const int32_t *tokens, const int32_t *species_row,
                               const int32_t *pos, const int32_t *attn_blocks, int n_blocks,
+                              const int32_t *row_panels, int n_panels,
                               const int32_t *cu_seqlens_host, int n_seq, float *logits, float *struct_logits,
                               float *rep_last, int32_t *status, void *workspace, size_t workspace_bytes,
                               void *stream);

@@ -220,3 +220,49 @@ def test_embed_with_row_statistics():
     rstd = 1.0 / torch.sqrt(v.var(1, unbiased=False) + 1e-5)
     np.testing.assert_allclose(rows[:, 0].cpu().numpy(), rstd.cpu().numpy(), rtol=2e-5)
     np.testing.assert_allclose(rows[:, 1].cpu().numpy(), (-rstd * v.mean(1)).cpu().numpy(), rtol=2e-5, atol=1e-6)
+
+
+def test_folded_qkv_product_on_row_panels():
+    """tc_gemm_ln_qkv_panels on a packed batch (sequences one after the other, every sequence cut into row panels
+    of at most 256 rows that start wherever the sequence starts) against tc_gemm_ln on the same sequences padded
+    to T = 512: same operands per row, same k order, same rotary recurrence from a multiple of 256 -> equal bits."""
+    lib = _lib.load()
+    x, gamma, beta, g = _inputs(21)
+    B = M // T
+    N = 3 * E
+    W = torch.randn(N, E, generator=g) * 0.02
+    bias = 0.02 * torch.randn(N, generator=g)
+    lens = torch.randint(1, T + 1, (B,), generator=g).tolist()
+    lens[:8] = [1, 255, 256, 257, 512, 511, 3, 300]                   # odd first rows, short and full last panels
+    ang = torch.arange(T, dtype=torch.float32)[:, None] * O.rope_freqs(64).float()[None, :]
+    cosg, sing = ang.cos().to(DEV).contiguous(), ang.sin().to(DEV).contiguous()
+    xg = x.to(DEV)
+    wf, s, c = _fold(lib, W.to(DEV), gamma.to(DEV), beta.to(DEV), bias.to(DEV))
+    xb = xg.to(torch.bfloat16)
+    rows = _rows_of(xb)
+    padded = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.tc_gemm_ln(_lib.TC_BF16, _lib.EPI_QKV_ROPE, xb.data_ptr(), E, wf.data_ptr(), c.data_ptr(), s.data_ptr(),
+                              rows.data_ptr(), padded.data_ptr(), N, M, N, E, 0.125, cosg.data_ptr(), sing.data_ptr(),
+                              T, 64, _stream()), "tc_gemm_ln")
+    keep = torch.cat([torch.arange(b * T, b * T + n) for b, n in enumerate(lens)]).to(DEV)
+    Mp = int(keep.numel())
+    xp = xb[keep].contiguous()
+    rows_p = rows[:M][keep].contiguous()                              # exactly Mp rows: the last panel's reads stay inside
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    panels = []
+    for b, n in enumerate(lens):
+        for k in range(0, n, 256):
+            panels.append([cu[b] + k, min(cu[b] + k + 256, cu[b + 1]), k, 0])
+    pan = torch.tensor(panels, dtype=torch.int32, device=DEV)
+    out = torch.full((Mp + 1, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.tc_gemm_ln_qkv_panels(_lib.TC_BF16, xp.data_ptr(), E, wf.data_ptr(), c.data_ptr(), s.data_ptr(),
+                                         rows_p.data_ptr(), out.data_ptr(), N, Mp, N, E, 0.125, cosg.data_ptr(),
+                                         sing.data_ptr(), T, 64, pan.data_ptr(), len(panels), _stream()),
+               "tc_gemm_ln_qkv_panels")
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out[Mp]).all())                           # nothing written past the last row
+    assert torch.equal(out[:Mp], padded[keep])
+    with pytest.raises(_lib.HipLibraryError):
+        _lib.check(lib.tc_gemm_ln_qkv_panels(_lib.TC_BF16, xp.data_ptr(), E, wf.data_ptr(), c.data_ptr(), s.data_ptr(),
+                                             rows_p.data_ptr(), out.data_ptr(), N, Mp, N, E, 0.125, cosg.data_ptr(),
+                                             sing.data_ptr(), T, 64, None, 0, _stream()), "tc_gemm_ln_qkv_panels")

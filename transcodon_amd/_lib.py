@@ -121,8 +121,10 @@ _SIGNATURES = {
     "tc_attn_fwd_packed": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_double, vp]),
     "tc_attn_fwd_packed_q2": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_double, vp]),
     "tc_mean_pool_packed": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
-    "tc_encoder_forward_packed": (C.c_int, [C.POINTER(EncoderDesc), vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp,
-                                            vp, C.c_size_t, vp]),
+    "tc_encoder_forward_packed": (C.c_int, [C.POINTER(EncoderDesc), vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int,
+                                            vp, vp, vp, vp, vp, C.c_size_t, vp]),
+    "tc_gemm_ln_qkv_panels": (C.c_int, [C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_float, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]),
     "tc_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc), C.c_int, C.c_int]),
     "tc_encoder_forward": (C.c_int, [C.POINTER(EncoderDesc), vp, vp, C.c_int, C.c_int, vp, vp, vp,
                                      C.c_int, C.POINTER(C.c_int32), C.POINTER(vp), vp, vp,

@@ -222,6 +222,7 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
 // per sequence (pos), attention runs per (sequence, query block) from the block list.
 extern "C" int tc_encoder_forward_packed(const tc_encoder_desc *d, const int32_t *tokens, const int32_t *species_row,
                                          const int32_t *pos, const int32_t *attn_blocks, int n_blocks,
+                                         const int32_t *row_panels, int n_panels,
                                          const int32_t *cu_seqlens_host, int n_seq, float *logits,
                                          float *struct_logits, float *rep_last, int32_t *status, void *workspace,
                                          size_t workspace_bytes, void *stream) {
@@ -231,7 +232,7 @@ extern "C" int tc_encoder_forward_packed(const tc_encoder_desc *d, const int32_t
     TC_REQUIRE(logits || rep_last, "tc_encoder_forward_packed: no output requested");
     TC_REQUIRE(n_seq > 0 && cu_seqlens_host[0] == 0, "tc_encoder_forward_packed: cu_seqlens must start at 0");
     const int qrows = tc_attn_packed_block_rows(d->dtype);
-    long want_blocks = 0;
+    long want_blocks = 0, want_panels = 0;
     int max_len = 0;
     double attn_flops = 0.0;
     for (int i = 0; i < n_seq; ++i) {
@@ -240,11 +241,15 @@ extern "C" int tc_encoder_forward_packed(const tc_encoder_desc *d, const int32_t
                    "tc_encoder_forward_packed: sequence %d has %ld tokens (1..%d, the rope table length)", i, len,
                    d->rope_table_len);
         want_blocks += (len + qrows - 1) / qrows;
+        want_panels += (len + 255) / 256;
         if (len > max_len) max_len = (int)len;
         attn_flops += 4.0 * d->H * 64.0 * (double)len * (double)len;
     }
     TC_REQUIRE(want_blocks == n_blocks, "tc_encoder_forward_packed: block list has %d entries, the lengths need %ld",
                n_blocks, want_blocks);
+    TC_REQUIRE(!row_panels || (want_panels == n_panels && tc_aligned16(row_panels)),
+               "tc_encoder_forward_packed: panel list has %d entries, the lengths need %ld (16-byte aligned)", n_panels,
+               want_panels);
     const long Ml = cu_seqlens_host[n_seq];
     TC_REQUIRE(Ml > 0 && Ml < (1L << 31), "tc_encoder_forward_packed: bad row count %ld", Ml);
     TC_REQUIRE(!struct_logits || (d->st_ln_g && d->st_ln_b && d->st_w && d->st_bias && d->n_struct > 0),
@@ -277,6 +282,13 @@ extern "C" int tc_encoder_forward_packed(const tc_encoder_desc *d, const int32_t
         const tc_layer_weights &lw = d->layers[l];
         fold2 = lw.w_fc1_ln && lw.c_fc1_ln && lw.s_fc1_ln;
     }
+    // With the list of row panels (every sequence cut into pieces of 256 rows) the q/k/v product also takes its
+    // folded form, and no LayerNorm kernel runs inside the layers, as in the padded forward.
+    bool fold1 = fold2 && row_panels != nullptr && d->rope_table_len >= 96;
+    for (int l = 0; l < d->num_layers && fold1; ++l) {
+        const tc_layer_weights &lw = d->layers[l];
+        fold1 = lw.w_qkv_ln && lw.c_qkv_ln && lw.s_qkv_ln;
+    }
     const float q_scale = bf ? 0.125f * 1.4426950408889634f : 0.125f;   // bf16: base-2 attention kernel
     auto attention = [&]() {
         return bf ? tc_attn_fwd_packed_q2(dt, w.qkv, 3 * E, attn_blocks, n_blocks, max_len, w.h, d->H, 64, attn_flops, stream)
@@ -290,16 +302,25 @@ extern "C" int tc_encoder_forward_packed(const tc_encoder_desc *d, const int32_t
                                d->vocab, d->n_species, d->pad_idx, w.xb, x_lo, w.ln_rows, d->ln_eps, stream));
         for (int l = 0; l < d->num_layers; ++l) {
             const tc_layer_weights &lw = d->layers[l];
-            TC_TRY(tc_layernorm_fwd_split(w.xb, x_lo, lw.ln1_g, lw.ln1_b, nullptr, w.h, M, E, d->ln_eps, stream));
-            TC_TRY(tc_gemm_qkv_packed(dt, w.h, E, lw.w_qkv, lw.b_qkv, w.qkv, 3 * E, M, 3 * E, E, q_scale, lw.rope_cos,
-                                      lw.rope_sin, pos, d->rope_table_len, 64, stream));
+            if (fold1) {
+                TC_TRY(tc_gemm_ln_qkv_panels(dt, w.xb, E, lw.w_qkv_ln, lw.c_qkv_ln, lw.s_qkv_ln, w.ln_rows, w.qkv, 3 * E, M,
+                                             3 * E, E, q_scale, lw.rope_cos, lw.rope_sin, d->rope_table_len, 64, row_panels,
+                                             n_panels, stream));
+            } else {
+                TC_TRY(tc_layernorm_fwd_split(w.xb, x_lo, lw.ln1_g, lw.ln1_b, nullptr, w.h, M, E, d->ln_eps, stream));
+                TC_TRY(tc_gemm_qkv_packed(dt, w.h, E, lw.w_qkv, lw.b_qkv, w.qkv, 3 * E, M, 3 * E, E, q_scale, lw.rope_cos,
+                                          lw.rope_sin, pos, d->rope_table_len, 64, stream));
+            }
             TC_TRY(attention());
             TC_TRY(tc_gemm_residual_split(dt, w.h, E, lw.w_o, lw.b_o, w.xb, x_lo, w.row_acc, E, M, E, E, stream));
             TC_TRY(tc_ln_rows_finalize(w.row_acc, w.ln_rows, M, E, d->ln_eps, stream));
             TC_TRY(tc_gemm_ln(dt, TC_EPI_BIAS_GELU, w.xb, E, lw.w_fc1_ln, lw.c_fc1_ln, lw.s_fc1_ln, w.ln_rows, w.mid,
                               w.ld_mid, M, F, E, 0.f, nullptr, nullptr, 0, 0, stream));
-            // no row sums here: the next layer's first LayerNorm is a kernel with its own statistics
-            TC_TRY(tc_gemm_residual_split(dt, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.xb, x_lo, nullptr, E, M, E, F, stream));
+            // row sums only when the next layer's first LayerNorm is folded too (a LayerNorm kernel takes its own)
+            const bool sums = fold1 && l + 1 < d->num_layers;
+            TC_TRY(tc_gemm_residual_split(dt, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.xb, x_lo, sums ? w.row_acc : nullptr, E, M,
+                                          E, F, stream));
+            if (sums) TC_TRY(tc_ln_rows_finalize(w.row_acc, w.ln_rows, M, E, d->ln_eps, stream));
         }
         TC_TRY(tc_layernorm_fwd_split(w.xb, x_lo, d->lnf_g, d->lnf_b, rep_last, (logits || !rep_last) ? w.h : nullptr, M, E,
                                       d->ln_eps, stream));

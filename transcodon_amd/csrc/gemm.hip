@@ -67,6 +67,11 @@ struct GemmParams {
     int gm;          // large-tile kernel: row panels per ordering group (1 = n-fastest)
     int gn;          // large-tile kernel: column panels per ordering group (tiles_n = no grouping)
     int cg_w0;       // alternating kernel: column panels of the first of two column groups (0 = one group)
+    // Packed batches on the alternating q/k/v kernel: row panel i of the launch is rows [panels[4i], panels[4i+1])
+    // (at most 256, all of one sequence, consecutive positions from panels[4i+2] on) instead of rows 256 i ..;
+    // tiles_m = n_panels, T = rows of the rotary tables.
+    const int32_t *panels;
+    int n_panels;
 #ifdef TC_GEMM_STAMPS
     unsigned long long *stamps;   // per workgroup: wait, issue, math, epilogue cycles (wave 0)
     int nostore;                  // experiment: the large-tile epilogue skips its final stores
@@ -1119,9 +1124,10 @@ constexpr bool piecewise_epilogue(int epi) {
 #define TC_GEMM_EARLY 0
 #endif
 
-template <typename T, int EPI, bool FOLD = false>
+template <typename T, int EPI, bool FOLD = false, bool PANELS = false>
 __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     using namespace k256x;
+    static_assert(!PANELS || (EPI == TC_EPI_QKV_ROPE && FOLD), "row panel lists: folded q/k/v product only");
     constexpr int kEarly = TC_GEMM_EARLY;      // MFMAs of a phase issued after its hand-over barrier
     static_assert(sizeof(T) == 2, "bf16 only");
     // Epilogues that read nothing from global memory (bias comes through LDS) run inside phase 0
@@ -1190,8 +1196,10 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     unsigned a1_src[2];                          // cursor 1 (k-tile g+1): A1
     unsigned b0_src[2], a0_src[2], b1_src[2];    // cursor 2 (k-tile g+2): B0, A0, B1
     auto a_src_of = [&](int tm, int h, int i) -> unsigned {
-        int gm = tm * BM + h * 128 + (wid * 2 + i) * 8 + srow;
-        gm = gm < p.M ? gm : p.M - 1;
+        int row0 = tm * BM, lim = p.M;
+        if constexpr (PANELS) { row0 = p.panels[4 * tm]; lim = p.panels[4 * tm + 1]; }
+        int gm = row0 + h * 128 + (wid * 2 + i) * 8 + srow;
+        gm = gm < lim ? gm : lim - 1;
         return (unsigned)gm * (unsigned)p.lda_bytes + schunk * 16;
     };
     auto b_src_of = [&](int tn, int h, int i) -> unsigned {
@@ -1249,14 +1257,33 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             glds16(reinterpret_cast<const char *>(vec + tn * BN + ((L >> 3) & 1) * 128 + wc * 32 + (L & 7) * 4), bias_slot);
         }
         if (ln_fold && wc == 0) {
-            // rows wr*64 .. +63 (lanes 0..31, two rows each) and 128 + wr*64 .. (lanes 32..63)
-            const int r0 = tm * BM + (L >> 5) * 128 + wr * 64 + (L & 31) * 2;
-            glds16(reinterpret_cast<const char *>(p.ln_rows + 2L * r0), rows_slot);
+            if constexpr (PANELS) {
+                // a panel may start at an odd row: four pieces of 32 rows, one float of a (rstd, -rstd mean) pair
+                // per lane (a 16-byte piece would need an even first row); reads stay inside the M rows
+                const int row0 = p.panels[4 * tm];
+                const long last = 2L * p.M - 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const long f = 2L * (row0 + (j >> 1) * 128 + wr * 64 + (j & 1) * 32) + L;
+                    __builtin_amdgcn_global_load_lds(TC_GLOBAL_PTR(reinterpret_cast<const char *>(p.ln_rows + (f < last ? f : last))),
+                                                     TC_LDS_PTR(rows_slot + j * 256), 4, 0, 0);
+                }
+            } else {
+                // rows wr*64 .. +63 (lanes 0..31, two rows each) and 128 + wr*64 .. (lanes 32..63)
+                const int r0 = tm * BM + (L >> 5) * 128 + wr * 64 + (L & 31) * 2;
+                glds16(reinterpret_cast<const char *>(p.ln_rows + 2L * r0), rows_slot);
+            }
         }
         if constexpr (EPI == TC_EPI_QKV_ROPE) {
             if ((tn * BN) / p.E < 2) {
                 // lane (fgrp, frow): row tile_pos0 + wr*64 + frow, pairs ((wc*32 + fgrp*8) % 64) / 2 .. + 3
-                const long e = (long)((tm * BM) % p.T + wr * 64 + frow) * 32 + (((wc * 32 + fgrp * 8) & 63) >> 1);
+                int trow = (tm * BM) % p.T + wr * 64 + frow;
+                if constexpr (PANELS) {
+                    // positions past the end of a short last panel belong to rows that are not stored
+                    trow = p.panels[4 * tm + 2] + wr * 64 + frow;
+                    trow = trow < p.T ? trow : p.T - 1;
+                }
+                const long e = (long)trow * 32 + (((wc * 32 + fgrp * 8) & 63) >> 1);
                 glds16(reinterpret_cast<const char *>(p.rope_cos + e), rope_slot);
                 glds16(reinterpret_cast<const char *>(p.rope_sin + e), rope_slot + 1024);
             }
@@ -1348,6 +1375,15 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     // epilogue of tile `local` (bias from this wave's LDS copy), accumulators back to zero
     auto finish_tile = [&](int tm, int tn) {
         const int mrow0 = tm * BM + wr * 64 + frow, ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);
+        if constexpr (PANELS) {
+            // the epilogue addresses row 256 tm + r of `out` and keeps rows below M: shift both to the panel
+            GemmParams q = p;
+            const int shift = p.panels[4 * tm] - tm * BM;
+            q.out = p.out + (long)shift * p.ldo * 2;
+            q.M = p.panels[4 * tm + 1] - shift;
+            epilogue256<T, EPI, kLay, 0, 8, 0, 4, true>(q, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, bias_slot, rope_slot,
+                                                        step_slot, rows_slot);
+        } else
         epilogue256<T, EPI, kLay, 0, 8, 0, 4, EPI == TC_EPI_QKV_ROPE || kGeluTable>(
             p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, lds_bias ? bias_slot : nullptr,
             kGeluTable ? smem + ROPE_OFF : rope_slot, step_slot, ln_fold ? rows_slot : nullptr);
@@ -1388,7 +1424,8 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             init_acc256<T, EPI, kLay, 0, 8, 0, 4, kSplit>(p, acc, mrow0, ncol0);
             if (wr == 1) TC_XBAR();
         }
-        const bool prev_full = kPiece && t > 0 && ptm * BM + BM <= p.M;
+        bool prev_full = kPiece && t > 0 && ptm * BM + BM <= p.M;
+        if constexpr (PANELS) prev_full = t > 0 && p.panels[4 * ptm + 1] - p.panels[4 * ptm] == BM;
 
         for (int kt = 0; kt < p.nk; ++kt, ++g) {
             const int cur = (g & 1) * DBUF_BYTES, nxt = DBUF_BYTES - cur;
@@ -1621,7 +1658,7 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
             }
             attr_set = true;
         }
-        p.tiles_m = (p.M + k256::BM - 1) / k256::BM;
+        p.tiles_m = p.panels ? p.n_panels : (p.M + k256::BM - 1) / k256::BM;
         p.tiles_n = p.N / k256::BN;
         const int ntiles = p.tiles_m * p.tiles_n;
         int grid = ntiles < g_num_cus ? ntiles : g_num_cus;
@@ -1658,7 +1695,25 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
         // the alternating kernel's rotary epilogue steps through a tile by angle addition: no
         // sequence boundary inside a 256-row tile, head dimension 64
         bool use_alt = alt != 0;
-        if (EPI == TC_EPI_QKV_ROPE && (p.T % 256 != 0 || p.head_dim != 64 || p.pos)) use_alt = false;
+        if (EPI == TC_EPI_QKV_ROPE && ((p.T % 256 != 0 && !p.panels) || p.head_dim != 64 || p.pos)) use_alt = false;
+        if (p.panels) {
+            // gemm_impl has checked: folded q/k/v product on the alternating schedule
+            if constexpr (EPI == TC_EPI_QKV_ROPE) {
+                static bool attr_set_p = false;
+                if (!attr_set_p) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256x_kernel<T, EPI, true, true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, k256x::LDS_BYTES);
+                    if (e != hipSuccess) {
+                        tc_set_error("tc_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                        return TC_ELAUNCH;
+                    }
+                    attr_set_p = true;
+                }
+                TC_LAUNCH((gemm256x_kernel<T, EPI, true, true>), dim3(grid), dim3(512), k256x::LDS_BYTES, stream, p);
+            }
+            TC_CHECK_LAUNCH("tc_gemm");
+            return TC_OK;
+        }
         constexpr bool kHasFold = EPI == TC_EPI_QKV_ROPE || EPI == TC_EPI_BIAS_GELU || EPI == TC_EPI_BIAS_RESIDUAL;
         if (use_alt && kHasFold && (EPI == TC_EPI_BIAS_RESIDUAL ? p.res_lo != nullptr : p.ln_rows != nullptr)) {
             if constexpr (kHasFold) {
@@ -1736,7 +1791,8 @@ static int gemm_impl(int dtype, int epilogue, const void *A, int lda, const void
                      const float *residual, const void *aux, void *out, void *out2, int ldo, int M, int N,
                      int K, int splits, float q_scale, const float *rope_cos, const float *rope_sin, int T,
                      int head_dim, void *stream, const int32_t *pos = nullptr, const float *ln_s = nullptr,
-                     const float *ln_rows = nullptr, unsigned long long *row_acc = nullptr, void *split_lo = nullptr) {
+                     const float *ln_rows = nullptr, unsigned long long *row_acc = nullptr, void *split_lo = nullptr,
+                     const int32_t *panels = nullptr, int n_panels = 0) {
     TC_REQUIRE(dtype == TC_BF16 || dtype == TC_F32, "tc_gemm: bad dtype %d", dtype);
     const int esz = dtype == TC_BF16 ? 2 : 4;
     const int kt = 128 / esz;
@@ -1796,7 +1852,7 @@ static int gemm_impl(int dtype, int epilogue, const void *A, int lda, const void
     }
     // the large tile needs N % 256 == 0 (and, for the fused q/k/v epilogue, E % 256 == 0 so that
     // a tile never straddles two sections) and enough tiles to occupy every CU
-    bool big = N % 256 == 0 && (long)((M + 255) / 256) * (N / 256) >= g_num_cus &&
+    bool big = N % 256 == 0 && (long)(panels ? n_panels : (M + 255) / 256) * (N / 256) >= g_num_cus &&
                (long)M * lda * esz < (1L << 32) && (long)N * K * esz < (1L << 32);
     if (epilogue == TC_EPI_QKV_ROPE && (N / 3) % 256 != 0) big = false;
     if (dtype != TC_BF16) big = false;   // the f32 path is MFMA-rate bound (1/16 of bf16): small tile is enough
@@ -1813,11 +1869,17 @@ static int gemm_impl(int dtype, int epilogue, const void *A, int lda, const void
     if (ln_s || ln_rows || row_acc) {
         // the folded LayerNorm lives in the alternating large-tile kernel's epilogues only
         bool ok = big && alt_schedule_enabled();
-        if (epilogue == TC_EPI_QKV_ROPE && (T % 256 != 0 || head_dim != 64 || pos)) ok = false;
+        if (epilogue == TC_EPI_QKV_ROPE && ((T % 256 != 0 && !panels) || head_dim != 64 || pos)) ok = false;
         TC_REQUIRE(ok, "tc_gemm: the folded LayerNorm needs the large alternating kernel (M=%d N=%d K=%d T=%d)", M, N, K, T);
         p.ln_s = ln_s;
         p.ln_rows = ln_rows;
         p.row_acc = row_acc;
+    }
+    if (panels) {
+        TC_REQUIRE(epilogue == TC_EPI_QKV_ROPE && ln_rows && big && n_panels > 0 && M >= 2 && tc_aligned16(panels),
+                   "tc_gemm: a row panel list goes with the folded q/k/v product on the large alternating kernel");
+        p.panels = panels;
+        p.n_panels = n_panels;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     // DGELU: out2 (optional, f32 [N]) receives += column sums of the result.  The large tile adds
@@ -1861,6 +1923,21 @@ extern "C" int tc_gemm_ln(int dtype, int epilogue, const void *A, int lda, const
     TC_REQUIRE(c && s && rows && tc_aligned16(s) && tc_aligned16(rows), "tc_gemm_ln: needs aligned c, s and row statistics");
     return gemm_impl(dtype, epilogue, A, lda, Wf, c, nullptr, nullptr, out, nullptr, ldo, M, N, K, 1, q_scale, rope_cos,
                      rope_sin, T, head_dim, stream, nullptr, s, rows, nullptr);
+}
+
+// The folded q/k/v product of a PACKED batch: row panel i of the launch is rows [panels[4i], panels[4i+1]) of A and
+// out: at most 256 rows of one sequence whose rotary positions run from panels[4i+2] on (panels[4i+3] unused), so
+// the table-slice rotary epilogue applies; a sequence of L rows contributes ceil(L / 256) panels, the last one
+// short.  panels: int32 [n_panels, 4] on the device, rows and positions inside [0, M) and [0, table_rows): the
+// caller's contract, not checked on the device.
+extern "C" int tc_gemm_ln_qkv_panels(int dtype, const void *A, int lda, const void *Wf, const float *c, const float *s,
+                                     const float *rows, void *out, int ldo, int M, int N, int K, float q_scale,
+                                     const float *rope_cos, const float *rope_sin, int table_rows, int head_dim,
+                                     const int32_t *panels, int n_panels, void *stream) {
+    TC_REQUIRE(c && s && rows && tc_aligned16(s) && tc_aligned16(rows), "tc_gemm_ln_qkv_panels: needs aligned c, s and row statistics");
+    TC_REQUIRE(panels && n_panels > 0 && table_rows >= 96, "tc_gemm_ln_qkv_panels: needs the panel list and rotary tables of 96 rows or more");
+    return gemm_impl(dtype, TC_EPI_QKV_ROPE, A, lda, Wf, c, nullptr, nullptr, out, nullptr, ldo, M, N, K, 1, q_scale, rope_cos,
+                     rope_sin, table_rows, head_dim, stream, nullptr, s, rows, nullptr, nullptr, panels, n_panels);
 }
 
 extern "C" int tc_gemm_residual_ln(int dtype, const void *A, int lda, const void *W, const float *bias,

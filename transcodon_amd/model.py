@@ -282,8 +282,9 @@ class ProteinBertModel(nn.Module):
 
     def packed_layout(self, species_type_ids, cu_seqlens, device):
         """Device-side index arrays of a packed batch (see forward_packed): rotary position and species
-        of every row, and the attention work list.  Depends only on the lengths and species, so a
-        caller that runs the same batch repeatedly builds it once."""
+        of every row, the attention work list, and the row panels of the q/k/v product (every sequence
+        cut into pieces of at most 256 rows: first row, end row, position of the first row).  Depends
+        only on the lengths and species, so a caller that runs the same batch repeatedly builds it once."""
         import numpy as np
         cu = np.asarray(cu_seqlens, dtype=np.int64)
         lens = np.diff(cu)
@@ -302,10 +303,17 @@ class ProteinBertModel(nn.Module):
         order = np.argsort(-lens[seq_of_block], kind="stable")          # longest sequences first: shorter tail
         blocks = np.zeros((len(qb), 4), np.int32)
         blocks[:, 0], blocks[:, 1], blocks[:, 2] = cu[seq_of_block][order], lens[seq_of_block][order], qb[order]
+        npan = (lens + 255) // 256
+        seq_of_panel = np.repeat(np.arange(n_seq), npan)
+        first = (np.arange(int(npan.sum())) - np.repeat(np.cumsum(npan) - npan, npan)) * 256   # position of the panel's first row
+        panels = np.zeros((len(first), 4), np.int32)
+        panels[:, 0] = cu[seq_of_panel] + first
+        panels[:, 1] = np.minimum(cu[seq_of_panel] + first + 256, cu[seq_of_panel + 1])
+        panels[:, 2] = first
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(device)
         return {"cu": np.ascontiguousarray(cu.astype(np.int32)), "n_seq": n_seq, "rows": M, "max_len": int(lens.max()),
                 "pos": up(pos), "species_row": up(np.repeat(sp, lens)), "blocks": up(blocks), "n_blocks": len(qb),
-                "dtype": self._dtype()}
+                "panels": up(panels), "n_panels": len(first), "dtype": self._dtype()}
 
     def forward_packed(self, tokens, species_type_ids, cu_seqlens, want_logits=True, want_struct=True,
                        want_representation=True, layout=None):
@@ -346,7 +354,8 @@ class ProteinBertModel(nn.Module):
         p = lambda t: None if t is None else t.data_ptr()
         check(lib.tc_encoder_forward_packed(
             C.byref(pk["desc"]), tok32.data_ptr(), lay["species_row"].data_ptr(), lay["pos"].data_ptr(),
-            lay["blocks"].data_ptr(), lay["n_blocks"], lay["cu"].ctypes.data, n_seq, p(logits), p(struct), p(rep),
+            lay["blocks"].data_ptr(), lay["n_blocks"], p(lay.get("panels")), lay.get("n_panels", 0),
+            lay["cu"].ctypes.data, n_seq, p(logits), p(struct), p(rep),
             status.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
             "tc_encoder_forward_packed")
         if self.check_indices and int(status.item()) != 0:
