@@ -116,6 +116,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_bf16_kernel(const AttnPar
     // number of key tiles up to the last one holding a valid key
     int nkt = nw;
     while (nkt > 0 && tile_word(nkt - 1) == 0ull) --nkt;
+#ifdef TC_ABL_NKT
+    nkt = nkt < TC_ABL_NKT ? nkt : TC_ABL_NKT;   // timing experiment: only the first key tiles
+#endif
 
     // ---- Q fragments: B operand, lane (q, h2) holds Q[q][16 ks + 8 h2 .. +7] ----
     bf16x8 qf[4];
