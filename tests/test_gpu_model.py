@@ -448,6 +448,38 @@ def test_packed_forward_large_batch_bf16(full_sd, full_bf16):
         assert float(d.max()) < 0.15
 
 
+def test_packed_forward_with_and_without_row_panels(full_bf16):
+    """The packed bf16 forward takes its q/k/v product over the layout's row panels (both LayerNorms of a layer
+    folded into the products); a layout without the panel list keeps the first LayerNorm a kernel and gathers
+    the rotary factors per row.  Same model, same rows: the two agree to the bf16 tolerance of the forward, and
+    the decoded codon choice is the same wherever the winning margin exceeds it."""
+    rng = np.random.default_rng(4242)
+    lens = np.clip(3 * np.exp(rng.normal(5.0, 0.7, 400)).astype(int) + 2, 3, 2000)
+    lens[:6] = [3, 255, 256, 257, 513, 1999]
+    lens = lens[np.cumsum(lens) <= 70000]
+    toks = np.concatenate([np.array([O.CLS] + list(rng.integers(5, 9, n - 2)) + [O.EOS]) for n in lens])
+    sp = rng.integers(0, 1438, len(lens))
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    lay = full_bf16.packed_layout(sp, cu, DEV)
+    assert lay["n_panels"] == int(((lens + 255) // 256).sum())
+    pan = lay["panels"].cpu().numpy()
+    assert (pan[:, 1] - pan[:, 0] <= 256).all() and (pan[:, 2] % 256 == 0).all()
+    assert int((pan[:, 1] - pan[:, 0]).sum()) == int(cu[-1])
+    bare = {k: v for k, v in lay.items() if k not in ("panels", "n_panels")}
+    flat = torch.from_numpy(toks).to(DEV)
+    with torch.no_grad():
+        a = full_bf16.forward_packed(flat, sp, cu, layout=lay)
+        b = full_bf16.forward_packed(flat, sp, cu, layout=bare)
+    d = (a["logits"] - b["logits"]).abs()
+    assert float(d.max()) <= 0.06, float(d.max())
+    assert float(d.pow(2).mean().sqrt()) <= 0.01
+    top = a["logits"].topk(2, dim=-1).values
+    sure = (top[:, 0] - top[:, 1]) > 0.12
+    assert bool((a["logits"].argmax(-1)[sure] == b["logits"].argmax(-1)[sure]).all())
+    dr = (a["representations"][12] - b["representations"][12]).abs().max()
+    assert float(dr) <= 0.2, float(dr)
+
+
 def test_cli_csv_round_trip(tmp_path):
     """python -m transcodon_amd.infer on a small CSV: same flags and columns as infer.py:229-302,
     predictions equal to the batched API and to the row-by-row embed_sequence path."""
