@@ -433,6 +433,9 @@ def main():
                     help="train = --config 4 (kept for older command lines)")
     ap.add_argument("--train-batch", type=int, default=64)
     ap.add_argument("--train-seq-len", type=int, default=1024)
+    ap.add_argument("--streams", type=int, choices=(1, 2), default=2,
+                    help="inference: HIP streams the captured forwards alternate on (2: consecutive micro-batches "
+                         "overlap at their kernels' tails; each stream has its own graph and workspace)")
     ap.add_argument("--no-graph", action="store_true",
                     help="inference configs: launch the forward kernel by kernel instead of replaying the captured HIP graph")
     ap.add_argument("--no-fold", action="store_true",
@@ -506,43 +509,77 @@ def main():
     host = {"tok": torch.from_numpy(tok_np).pin_memory(), "sp": torch.from_numpy(sp_np).pin_memory(),
             "aa": torch.frombuffer(bytearray(codes), dtype=torch.uint8).pin_memory(),
             "offs": torch.from_numpy(offs).pin_memory(), "row0": torch.from_numpy(row0).pin_memory()}
-    d = {k: v.to(dev) for k, v in host.items()}
+    # one set of device input buffers per stream (the step with host I/O refills the set of the stream it runs on)
+    dsets = [{k: v.to(dev) for k, v in host.items()} for _ in range(args.streams if not args.no_graph else 1)]
+    d = dsets[0]
     n_seq = tok_np.shape[0]
     bases_host = torch.empty(3 * len(codes), dtype=torch.uint8).pin_memory()
 
     # per micro-batch views / rebased offsets, made before the clock starts
-    mbs = []
+    def views(ds):
+        out = []
+        for i in range(n_micro):
+            lo_s, hi_s = i * B, min((i + 1) * B, n_seq)
+            a0, a1 = int(offs[lo_s]), int(offs[hi_s])
+            out.append((ds["tok"][lo_s:hi_s], ds["sp"][lo_s:hi_s], ds["aa"][a0:a1], lo_s, hi_s, a0, a1))
+        return out
+    # (offsets relative to the micro-batch do not change with the step: made once)
+    rel = []
     for i in range(n_micro):
         lo_s, hi_s = i * B, min((i + 1) * B, n_seq)
-        a0, a1 = int(offs[lo_s]), int(offs[hi_s])
-        mbs.append((d["tok"][lo_s:hi_s], d["sp"][lo_s:hi_s], d["aa"][a0:a1],
-                    (d["offs"][lo_s:hi_s + 1] - a0).contiguous(), (d["row0"][lo_s:hi_s] - lo_s * T).contiguous(),
-                    a0, a1))
+        a0 = int(offs[lo_s])
+        rel.append(((d["offs"][lo_s:hi_s + 1] - a0).contiguous(), (d["row0"][lo_s:hi_s] - lo_s * T).contiguous()))
+    mbs_of = [views(ds) for ds in dsets]
 
     # The forward of a full micro-batch is replayed from one HIP graph (ProteinBertModel.capture_forward: the same
     # launches, recorded once); a refused capture falls back to the eager call and says so in the result.
-    graphed, graph_err = None, None
+    # With two streams every stream has its own graph and its own workspace (the graphs of one model otherwise
+    # share the model's), and consecutive micro-batches alternate between them: nothing orders one against the
+    # other, so the next forward's first kernels fill the CUs that the previous one's last kernels leave idle.
+    graphs, graph_err = [], None
     if not args.no_graph:
         try:
-            graphed = model.capture_forward(B, T)
+            graphs = [model.capture_forward(B, T, private_workspace=args.streams > 1) for _ in range(args.streams)]
         except Exception as e:
-            graph_err = f"{type(e).__name__}: {e}"
+            graphs, graph_err = [], f"{type(e).__name__}: {e}"
+    graphed = graphs[0] if graphs else None
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(len(graphs))] if len(graphs) > 1 else []
+    turn = [0]
 
-    def micro(i, use_graph):
-        """Forward + decode of micro-batch i of this rank's shard; returns the decoded bases."""
-        tok_i, sp_i, aa_i, offs_i, row0_i, a0, a1 = mbs[i]
+    def micro(i, use_graph, which=0):
+        """Forward + decode of micro-batch i of this rank's shard (inputs of buffer set `which`); returns the decoded bases."""
+        tok_i, sp_i, aa_i, _, _, a0, a1 = mbs_of[which][i]
+        offs_i, row0_i = rel[i]
         if use_graph and graphed is not None and tok_i.shape[0] == B:
-            out = graphed(tok_i, sp_i, check_indices=False)
+            g = graphs[turn[0] % len(graphs)]
+            out = g(tok_i, sp_i, check_indices=False)
         else:
             with torch.no_grad():
                 out = model(tok_i, sp_i)
         return ops.codon_decode(out["logits"].view(tok_i.shape[0] * T, -1), aa_i, offs_i, row0_i), a0, a1
 
-    def step(host_io=False, use_graph=True):
-        if host_io:      # token ids, species and residues come from the host; decoded bases go back
+    def step(host_io=False, use_graph=True, overlap=True):
+        laned = bool(lanes) and use_graph and overlap
+        if host_io and not laned:      # token ids, species and residues come from the host; decoded bases go back
             for k in ("tok", "sp", "aa", "offs", "row0"):
                 d[k].copy_(host[k], non_blocking=True)
         for i in range(n_micro):
+            if laned:
+                which = turn[0] % len(lanes)
+                with torch.cuda.stream(lanes[which]):
+                    if host_io:                            # this micro-batch's part of the inputs, on its own stream
+                        _, _, _, lo_s, hi_s, a0, a1 = mbs_of[which][i]
+                        ds = dsets[which]
+                        ds["tok"][lo_s:hi_s].copy_(host["tok"][lo_s:hi_s], non_blocking=True)
+                        ds["sp"][lo_s:hi_s].copy_(host["sp"][lo_s:hi_s], non_blocking=True)
+                        ds["aa"][a0:a1].copy_(host["aa"][a0:a1], non_blocking=True)
+                        ds["offs"][lo_s:hi_s + 1].copy_(host["offs"][lo_s:hi_s + 1], non_blocking=True)
+                        ds["row0"][lo_s:hi_s].copy_(host["row0"][lo_s:hi_s], non_blocking=True)
+                    bases, a0, a1 = micro(i, use_graph, which)
+                    if host_io:
+                        bases_host[3 * a0:3 * a1].copy_(bases, non_blocking=True)
+                turn[0] += 1
+                continue
             bases, a0, a1 = micro(i, use_graph)
             if host_io:
                 bases_host[3 * a0:3 * a1].copy_(bases, non_blocking=True)
@@ -571,6 +608,9 @@ def main():
     lib.tc_prof_enable(0)
     elapsed, bases = timed(args.steps)                      # the headline: no per-kernel timers
     elapsed_io, _ = timed(args.steps, host_io=True)         # the same with H2D of the inputs and D2H of the bases
+    elapsed_one, bases_one = timed(args.steps, overlap=False)         # the graphs one after the other on one stream
+    if not torch.equal(bases_one, bases):
+        raise SystemExit("bench: the overlapped and the one-stream step decode different bases")
     elapsed_eager, bases_eager = timed(args.steps, use_graph=False)   # the same step launched kernel by kernel
     if graphed is not None and not torch.equal(bases_eager, bases):
         raise SystemExit(f"bench: the graph replay and the eager step decode different bases "
@@ -639,8 +679,10 @@ def main():
                                      else "separate kernels"),
                        "with_host_io_tokens_per_s": round(tokens_total / elapsed_io, 1),
                        "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3),
-                       "launch": ("one HIP graph per forward (ProteinBertModel.capture_forward), decode kernel eager"
+                       "launch": ((f"one HIP graph per forward (ProteinBertModel.capture_forward), decode kernel eager; "
+                                   f"{len(graphs)} graph(s) with private workspaces alternating on {max(1, len(lanes))} stream(s)")
                                   if graphed is not None else "eager, kernel by kernel"),
+                       "one_stream_ms_per_step": round(1e3 * elapsed_one / args.steps, 3),
                        "eager_ms_per_step": round(1e3 * elapsed_eager / args.steps, 3),
                        "hip_graph_error": graph_err},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel<bf16, EPI> (all GEMM launches of the step)",

@@ -276,9 +276,9 @@ class ProteinBertModel(nn.Module):
             raise IndexError("token or species id out of range")
         return out
 
-    def capture_forward(self, B, T, repr_layers=(12,), device=None):
+    def capture_forward(self, B, T, repr_layers=(12,), device=None, private_workspace=False):
         """The inference forward of a fixed batch shape as ONE HIP graph (see GraphedForward)."""
-        return GraphedForward(self, B, T, repr_layers, device)
+        return GraphedForward(self, B, T, repr_layers, device, private_workspace)
 
     def packed_layout(self, species_type_ids, cu_seqlens, device):
         """Device-side index arrays of a packed batch (see forward_packed): rotary position and species
@@ -423,9 +423,13 @@ class GraphedForward:
     graph's static buffers, replays the graph and returns the same dict as ``forward``; the tensors in
     it are the graph's own output buffers and are overwritten by the next call (clone what must live
     longer).  Weights are read at replay time, so ``load_state_dict`` into the same parameters needs no
-    new capture; ``set_compute_dtype`` or another shape does."""
+    new capture; ``set_compute_dtype`` or another shape does.
 
-    def __init__(self, model, B, T, repr_layers=(12,), device=None):
+    The kernels of a graph work in the model's workspace, so two graphs of one model may not run at the same
+    time -- unless they are captured with ``private_workspace=True``: such a graph owns its workspace, and two
+    of them replayed on two streams overlap (the tail of one forward's kernels with the next one's)."""
+
+    def __init__(self, model, B, T, repr_layers=(12,), device=None, private_workspace=False):
         dev = torch.device(device) if device is not None else next(model.parameters()).device
         if dev.type != "cuda":
             raise _lib.HipLibraryError("GraphedForward needs the model on the GPU (there is no CPU fallback)")
@@ -434,6 +438,16 @@ class GraphedForward:
         self.tokens[:, 0] = model.cls_idx
         self.species = torch.zeros(self.B, dtype=torch.int32, device=dev)
         repr_layers = list(repr_layers)
+        shared_ws = model._workspace
+        if private_workspace:
+            model._workspace = None                 # the calls below allocate a workspace that this graph keeps
+        try:
+            self._capture(model, dev, repr_layers)
+        finally:
+            if private_workspace:
+                self._workspace, model._workspace = model._workspace, shared_ws
+
+    def _capture(self, model, dev, repr_layers):
         with torch.no_grad():
             # first calls outside the capture: weight packing, workspace, one-time kernel attributes
             side = torch.cuda.Stream(device=dev)
