@@ -272,20 +272,30 @@ def bench_varlen(args, world, rank, dev, dist_on, rccl_ranks=1):
     my_tokens = int(lens_all[mine].sum())
     flops_step = float(sum(12 * (14155776 * int(t) + 3072 * int(t) * int(t)) for t in lens_all[mine]))   # no heads
 
-    def step():
-        for tok, lay, start, ln in prepared:
+    # Batches alternate between two streams, each with its own workspace slot: the first kernels of a batch fill
+    # the CUs that the last kernels of the batch before leave idle (--streams 1: one stream, one workspace).
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else []
+
+    def step(overlap=True):
+        for j, (tok, lay, start, ln) in enumerate(prepared):
+            if lanes and overlap:
+                k = j % len(lanes)
+                with torch.cuda.stream(lanes[k]), model.workspace_slot(k), torch.no_grad():
+                    rep = model.forward_packed(tok, None, None, want_logits=False, layout=lay)["representations"][12]
+                    pooled = ops.mean_pool_packed(rep, start, ln)
+                continue
             with torch.no_grad():
                 rep = model.forward_packed(tok, None, None, want_logits=False, layout=lay)["representations"][12]
             pooled = ops.mean_pool_packed(rep, start, ln)
         return pooled
 
-    def timed(n):
+    def timed(n, overlap=True):
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
-            step()
+            step(overlap)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if dist_on:
@@ -300,10 +310,11 @@ def bench_varlen(args, world, rank, dev, dist_on, rccl_ranks=1):
         step()
     lib.tc_prof_enable(0)
     elapsed = timed(args.steps)
+    elapsed_one = timed(args.steps, overlap=False)         # the same batches one after the other on one stream
     lib.tc_prof_reset()
     lib.tc_prof_enable(1)
-    elapsed_prof = timed(args.steps)
-    lib.tc_prof_enable(0)
+    elapsed_prof = timed(args.steps, overlap=False)        # per-kernel device times: one stream, so that no kernel's
+    lib.tc_prof_enable(0)                                  # interval contains another stream's work
     n, ms, flops = _lib.prof_collect(_lib.PROF_GEMM)
     an, ams, aflops = _lib.prof_collect(_lib.PROF_ATTN)
     ln_n, ln_ms, ln_bytes = _lib.prof_collect(_lib.PROF_LAYERNORM)
@@ -319,9 +330,10 @@ def bench_varlen(args, world, rank, dev, dist_on, rccl_ranks=1):
                                    "clipped to [30, 2048], seed 1237; the full configuration is --n-seqs 100000), packed "
                                    "without padding rows in batches of <= 131072 tokens, mean-pooled final states",
                        "n_seqs": n_total, "tokens": int(lens_all.sum()), "mean_len": round(float(lens_all.mean()), 1),
-                       "batches_per_step_rank0": len(prepared), "parallelism": f"sequence-sharded x{world}",
+                       "batches_per_step_rank0": len(prepared), "streams": max(1, len(lanes)), "parallelism": f"sequence-sharded x{world}",
                        "rccl_ranks": rccl_ranks, "backend": args.backend if world > 1 else None, "seqs_per_s": round(n_total * args.steps / elapsed, 1),
                        "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3),
+                       "one_stream_ms_per_step": round(1e3 * elapsed_one / args.steps, 3),
                        "layernorm": "both LayerNorms of every layer folded into the q/k/v and fc1 products (q/k/v over row panels of "
                                     "<= 256 rows per sequence), residual stream as bf16 hi/lo planes; the final one is a kernel"},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel / gemm256_kernel (all GEMM launches of the step)",

@@ -480,6 +480,60 @@ def test_packed_forward_with_and_without_row_panels(full_bf16):
     assert float(dr) <= 0.2, float(dr)
 
 
+def test_forwards_on_two_streams_with_their_own_workspaces(full_bf16):
+    """Two captured forwards with private workspaces replayed on two streams, and two packed forwards in two
+    workspace slots, run side by side (nothing orders one stream against the other): every result equals the
+    one-at-a-time result bit for bit, also when the same graph is replayed again right behind."""
+    m = full_bf16
+    rng = np.random.default_rng(77)
+    B, T = 64, 512
+    toks = [torch.from_numpy(rng.integers(5, 9, (B, T))).to(DEV) for _ in range(2)]
+    for t in toks:
+        t[:, 0], t[:, -1] = O.CLS, O.EOS
+    sps = [torch.from_numpy(rng.integers(0, 1438, B)).to(DEV) for _ in range(2)]
+    with torch.no_grad():
+        want = [m(t, s)["logits"].clone() for t, s in zip(toks, sps)]
+    graphs = [m.capture_forward(B, T, private_workspace=True) for _ in range(2)]
+    assert graphs[0]._workspace.data_ptr() != graphs[1]._workspace.data_ptr()
+    lanes = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    got = [[], []]
+    for rnd in range(3):
+        for k in range(2):
+            with torch.cuda.stream(lanes[k]):
+                got[k].append(graphs[k](toks[k], sps[k], check_indices=False)["logits"].clone())
+    torch.cuda.synchronize()
+    for k in range(2):
+        for g in got[k]:
+            assert torch.equal(g, want[k])
+    # packed batches in two workspace slots
+    lens = [np.clip(3 * np.exp(rng.normal(5.0, 0.6, 200)).astype(int) + 2, 30, 1500) for _ in range(2)]
+    lens = [l[np.cumsum(l) <= 40000] for l in lens]
+    flat = [torch.from_numpy(np.concatenate([np.array([O.CLS] + list(rng.integers(5, 9, n - 2)) + [O.EOS]) for n in l])).to(DEV)
+            for l in lens]
+    sp = [rng.integers(0, 1438, len(l)) for l in lens]
+    cu = [np.concatenate([[0], np.cumsum(l)]) for l in lens]
+    lay = [m.packed_layout(sp[k], cu[k], DEV) for k in range(2)]
+    old_check, m.check_indices = m.check_indices, False
+    try:
+        with torch.no_grad():
+            want_p = [m.forward_packed(flat[k], None, None, want_logits=False, layout=lay[k])["representations"][12].clone()
+                      for k in range(2)]
+            torch.cuda.synchronize()
+            got_p = [[], []]
+            for rnd in range(3):
+                for k in range(2):
+                    with torch.cuda.stream(lanes[k]), m.workspace_slot(k):
+                        got_p[k].append(m.forward_packed(flat[k], None, None, want_logits=False,
+                                                         layout=lay[k])["representations"][12])
+            torch.cuda.synchronize()
+    finally:
+        m.check_indices = old_check
+    for k in range(2):
+        for g in got_p[k]:
+            assert torch.equal(g, want_p[k])
+
+
 def test_cli_csv_round_trip(tmp_path):
     """python -m transcodon_amd.infer on a small CSV: same flags and columns as infer.py:229-302,
     predictions equal to the batched API and to the row-by-row embed_sequence path."""

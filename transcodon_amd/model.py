@@ -6,6 +6,7 @@ padded batch is ONE call into libtranscodon_hip.so (tc_encoder_forward); PyTorch
 the parameters, the output buffers and the stream.
 """
 
+import contextlib
 import ctypes as C
 
 import torch
@@ -220,6 +221,20 @@ class ProteinBertModel(nn.Module):
             out[f"w_{tag}_ln"], out[f"s_{tag}_ln"], out[f"c_{tag}_ln"] = wf, s, c
         torch.cuda.current_stream(device).synchronize()      # W and the temporaries may be freed after this
         return out
+
+    @contextlib.contextmanager
+    def workspace_slot(self, k):
+        """Forward calls inside the block work in workspace number ``k`` (kept between uses) instead of the
+        model's default one.  The kernels of two forwards that run at the same time -- on two streams -- must
+        not share a workspace: give each stream its own slot."""
+        slots = self.__dict__.setdefault("_workspace_slots", {})
+        saved = self._workspace
+        self._workspace = slots.get(k)
+        try:
+            yield self
+        finally:
+            slots[k] = self._workspace
+            self._workspace = saved
 
     def _get_workspace(self, nbytes, device, train=False):
         attr = "_train_workspace" if train else "_workspace"
