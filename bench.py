@@ -445,7 +445,7 @@ def main():
                     help="train = --config 4 (kept for older command lines)")
     ap.add_argument("--train-batch", type=int, default=64)
     ap.add_argument("--train-seq-len", type=int, default=1024)
-    ap.add_argument("--streams", type=int, choices=(1, 2), default=2,
+    ap.add_argument("--streams", type=int, choices=(1, 2, 3, 4), default=2,
                     help="inference: HIP streams the captured forwards alternate on (2: consecutive micro-batches "
                          "overlap at their kernels' tails; each stream has its own graph and workspace)")
     ap.add_argument("--no-graph", action="store_true",
