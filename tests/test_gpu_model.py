@@ -234,13 +234,14 @@ def test_testcsv_f32_codon_agreement(golden_dir, full_f32, key, packed):
     assert diff <= max(2, total // 1000), (diff, total)
 
 
-def test_headline_kernel_mix_bf16_against_oracle(full_sd, full_bf16):
+@pytest.mark.parametrize("B,T,rows", [(64, 512, [0, 17, 63]), (32, 1024, [3, 31])])
+def test_headline_kernel_mix_bf16_against_oracle(full_sd, full_bf16, B, T, rows):
     """64 x 512 tokens in bf16: the shapes that take the persistent 256 x 256 GEMM kernels, the
     LDS-staged rotary epilogue (T % 256 == 0), the 8-wave attention kernel and head_rows_kernel, i.e.
-    the kernel mix of the 256 x 512 headline batch.  Sequences are independent, so the CPU oracle
-    only runs the rows that are compared."""
-    rng = np.random.default_rng(4321)
-    B, T = 64, 512
+    the kernel mix of the 256 x 512 headline batch; 32 x 1024 is the row length of the 4096 x 1024
+    batch-sharded configuration (four rotary slices and sixteen key tiles per sequence).  Sequences
+    are independent, so the CPU oracle only runs the rows that are compared."""
+    rng = np.random.default_rng(4321 + T)
     tok = np.empty((B, T), np.int64)
     for b in range(B):
         u = int(rng.integers(20, 101))
@@ -249,7 +250,6 @@ def test_headline_kernel_mix_bf16_against_oracle(full_sd, full_bf16):
     sp = rng.integers(0, 1438, B)
     with torch.no_grad():
         out = full_bf16(torch.from_numpy(tok).to(DEV), torch.from_numpy(sp).to(DEV))
-    rows = [0, 17, 63]
     ref = O.forward(full_sd, O.FULL, torch.from_numpy(tok[rows]), torch.from_numpy(sp[rows]))
     keep = np.ones((len(rows), T), bool)
     _check(out["logits"][rows].cpu().numpy(), ref["logits"].numpy(), keep, torch.bfloat16)
