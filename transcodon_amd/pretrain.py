@@ -145,6 +145,15 @@ class Trainer:
             with torch.no_grad():
                 sums[0] += mask_loss.detach()
                 sums[2] += total.detach()
+        if self.world > 1:
+            # The gradient mean covers the structure head on every rank, so every rank must take the same
+            # decision about updating it: labels seen by any rank count for all (DDP hands the averaged
+            # gradient of a parameter to the ranks that did not use it, pretraining.py:243).
+            import torch.distributed as dist
+            if dist.is_initialized():
+                flag = torch.tensor([1.0 if any_struct else 0.0], device=self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                any_struct = bool(flag.item() > 0)
         factor = self.lr_factor(self.global_step)
         self.opt.step(lr_factor=factor, exclude=() if any_struct else self.struct_params)
         self.global_step += 1
