@@ -102,7 +102,7 @@ def cpu_baseline(sd_cpu, tok, species, codes_per_seq, threads):
                 O.decode(out["logits"][b, start:start + 3 * len(aa)], aa)
         dt = time.perf_counter() - t0
     return {"value": round(n_seq * t.shape[1] * iters / dt, 1), "unit": "tokens/s", "cores": threads,
-            "kind": "port",
+            "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": f"{n_seq} seqs x {t.shape[1]} tokens x {iters} iters, torch fp32 oracle forward + decode, {dt:.1f} s"}
 
 
@@ -338,7 +338,9 @@ def bench_varlen(args, world, rank, dev, dist_on, rccl_ranks=1):
                                     "<= 256 rows per sequence), residual stream as bf16 hi/lo planes; the final one is a kernel"},
             "roofline": {"bound": "mfma", "kernel": "gemm256x_kernel / gemm256_kernel (all GEMM launches of the step)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n,
+                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "traffic_source": "not collected for this configuration (no counter pass of this command is committed)",
+                         "launches": n,
                          "avg_launch_us": round(1e3 * ms / max(n, 1), 2), "ms_per_step": round(ms / args.steps, 3),
                          "whole_forward_tflops": round(flops_step * args.steps / elapsed / 1e12, 2),
                          "whole_forward_frac": round(flops_step * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4)},
@@ -689,7 +691,10 @@ def main():
                        "rccl_ranks": rccl_ranks, "backend": args.backend if world > 1 else None,
                        "layernorm": ("24 of 25 folded into the q/k/v, out-proj, fc1 and fc2 products, residual stream as bf16 hi/lo planes" if folded
                                      else "separate kernels"),
-                       "with_host_io_tokens_per_s": round(tokens_total / elapsed_io, 1),
+                       "value_definition": ("tokens/s with token ids, species and residues already resident in HBM and the "
+                                            "decoded bases left there; the same steps with the H2D copy of the inputs and the "
+                                            "D2H copy of the decoded bases inside the timed region are value_with_host_io"),
+                       "value_with_host_io": round(tokens_total / elapsed_io, 1),
                        "with_kernel_timers_ms_per_step": round(1e3 * elapsed_prof / args.steps, 3),
                        "launch": ((f"one HIP graph per forward (ProteinBertModel.capture_forward), decode kernel eager; "
                                    f"{len(graphs)} graph(s) with private workspaces alternating on {max(1, len(lanes))} stream(s)")
@@ -702,7 +707,9 @@ def main():
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
                          "traffic": pmc_traffic(pmc) if pmc and args.config == 2 else None,
                          "mfma_busy_pmc": pmc_mfma_busy(pmc) if pmc and args.config == 2 else None,
-                         "traffic_unit": TRAFFIC_UNIT, "traffic_source": pmc and "profiles/" + pmc,
+                         "traffic_unit": TRAFFIC_UNIT,
+                         "traffic_source": ("profiles/" + pmc) if pmc and args.config == 2 else
+                                           "not collected for this configuration (no counter pass of this command is committed)",
                          "algorithmic_bytes_per_launch": round(gemm_bytes / max(n, 1)),
                          "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
                          "ms_per_step": round(ms / args.steps, 3),

@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define TC_VERSION 100
+/* Changes whenever a struct layout or a signature of this header changes; a caller built against another
+ * value must not call into the library.  tc_struct_bytes lets a binding that restates the structs (ctypes)
+ * verify its own layout: which = 0 tc_layer_weights, 1 tc_encoder_desc, 2 tc_layer_grads, 3 tc_encoder_grads. */
+#define TC_VERSION 120
 
 /* status codes */
 #define TC_OK 0
@@ -52,6 +55,7 @@ extern "C" {
 #define TC_EPI_DGELU 6           /* out = (A W^T) * gelu'(aux)   (gradient through the GELU)    */
 
 int tc_version(void);
+size_t tc_struct_bytes(int which);
 const char *tc_last_error(void);
 
 /*
@@ -330,6 +334,11 @@ int tc_attn_bwd(int dtype, const void *qkv, int ldq, const uint64_t *key_words, 
  * frees nothing.  All calls on one GPU share the array: calls that overlap on one GPU (different
  * streams or threads) race; calls in stream order on one stream do not.  Results equal tc_attn_bwd's.
  */
+/* Resolves, for the CURRENT device, the address of that array (hipGetSymbolAddress).  The first
+ * tc_attn_bwd_static call on a device does the same by itself, but that first call must then happen
+ * outside stream capture; a caller that captures graphs calls tc_init_device once per device beforehand.
+ * No counterpart in the reference. */
+int tc_init_device(void);
 int tc_attn_bwd_static(int dtype, const void *qkv, int ldq, const uint64_t *key_words, const void *out,
                        const void *d_out, const float *lse, void *d_qkv, int ldg, const float *rope_cos,
                        const float *rope_sin, float q_scale, int B, int T, int H, int D, void *stream);

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert set(_lib.EXPORTED_SYMBOLS) == declared
-    assert _lib.load().tc_version() == 100
+    assert _lib.load().tc_version() == _lib.ABI_VERSION
 
 
 def test_alphabet_matches_reference_facts():

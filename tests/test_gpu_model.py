@@ -657,6 +657,68 @@ def test_graph_replays_back_to_back_with_folded_layernorms(full_bf16):
         assert torch.equal(r3, eager["representations"][3]), n
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_graph_follows_weight_changes_and_workspace_regrowth(dtype):
+    """A captured forward addresses the model's packed weights and workspace by raw pointers.  After
+    load_state_dict with other weights, after an eager forward that makes the model's workspace grow,
+    and after an AdamW step on a flat parameter store, the next replay must give what the eager forward
+    gives on the weights as they are now (the graph keeps what it addresses alive and is captured again
+    when the weights changed), and must not be captured again when nothing changed."""
+    from transcodon_amd.train import AdamW, FlatParameters
+    cfg = O.TINY
+    m = _model(cfg, seeded_state_dict(cfg, 3, perturb=True), dtype)
+    rng = np.random.default_rng(5)
+    B, T = 3, 64
+    tok = np.full((B, T), O.PAD, np.int64)
+    for b, n in enumerate((T, 40, 17)):
+        tok[b, :n] = [O.CLS] + list(rng.choice([5, 6, 7, 8, 9], n - 2)) + [O.EOS]
+    tok_d = torch.from_numpy(tok).to(DEV)
+    sp_d = torch.from_numpy(rng.integers(0, cfg.species_vocab_size, B)).to(DEV)
+    keep = tok_d != O.PAD
+
+    def same(graphed):
+        got = {k: v.clone() for k, v in graphed(tok_d, sp_d).items() if k != "representations"}
+        with torch.no_grad():
+            eager = m(tok_d, sp_d)
+        for k in got:
+            assert torch.equal(got[k][keep], eager[k][keep]), k
+        return got["logits"]
+
+    graphed = m.capture_forward(B, T)
+    first = same(graphed)
+    same(graphed)
+    assert graphed.captures == 1
+    # other weights into the same parameters
+    m.load_state_dict(seeded_state_dict(cfg, 4, perturb=True), strict=True)
+    second = same(graphed)
+    assert graphed.captures == 2
+    assert not torch.equal(first[keep], second[keep])
+    # the model's shared workspace is replaced by a larger one; junk goes through the freed blocks
+    with torch.no_grad():
+        m(torch.from_numpy(rng.integers(5, 9, (8, 512))).to(DEV), torch.zeros(8, dtype=torch.int64, device=DEV))
+    junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(8)]
+    third = same(graphed)
+    assert torch.equal(second[keep], third[keep]) and graphed.captures == 2
+    del junk
+    # parameters re-homed into a flat store, then changed by the optimiser kernel behind torch's back
+    for p in m.parameters():
+        p.requires_grad_(True)
+    store = FlatParameters(m)
+    opt = AdamW(store, lr=0.05)
+    fourth = same(graphed)
+    assert torch.allclose(third[keep], fourth[keep], atol=1e-6)
+    n_cap = graphed.captures
+    store.grad.normal_(generator=torch.Generator(device=DEV).manual_seed(1))
+    opt.step()
+    fifth = same(graphed)
+    assert graphed.captures == n_cap + 1
+    assert not torch.allclose(fourth[keep], fifth[keep], atol=1e-4)
+    # a frozen graph (check_weights off) keeps replaying and is the caller's promise
+    graphed.check_weights = False
+    graphed(tok_d, sp_d)
+    assert graphed.captures == n_cap + 1
+
+
 def test_headline_size_determinism_and_batch_permutation(full_bf16):
     """At the headline size (256 sequences x 512 tokens, the folded-LayerNorm kernels): two forwards of the same
     batch are bit-identical (the fold's row sums are integer atomics, nothing else accumulates across

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TC_LIB_PATH points at another build of the same library (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(_HERE, "csrc", "libtranscodon_hip.so")
 
+ABI_VERSION = 120          # TC_VERSION of include/transcodon_hip.h this binding restates
 TC_F32, TC_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_QKV_ROPE = 0, 1, 2, 3
 EPI_PLAIN_F32, EPI_BIAS_GELU_SAVE, EPI_DGELU = 4, 5, 6
@@ -63,6 +64,8 @@ class HipLibraryError(RuntimeError):
 
 _SIGNATURES = {
     "tc_version": (C.c_int, []),
+    "tc_struct_bytes": (C.c_size_t, [C.c_int]),
+    "tc_init_device": (C.c_int, []),
     "tc_last_error": (C.c_char_p, []),
     "tc_embed_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
     "tc_embed_fwd_ln": (C.c_int, [vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 6 + [vp, vp, vp, C.c_float, vp]),
@@ -167,6 +170,13 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        if lib.tc_version() != ABI_VERSION:
+            raise HipLibraryError(f"{LIB_PATH} has ABI version {lib.tc_version()}, this binding was written for "
+                                  f"{ABI_VERSION}: rebuild it with `make -C transcodon_amd/csrc`")
+        for which, struct in enumerate((LayerWeights, EncoderDesc, LayerGrads, EncoderGrads)):
+            if lib.tc_struct_bytes(which) != C.sizeof(struct):
+                raise HipLibraryError(f"{struct.__name__}: {C.sizeof(struct)} bytes here, "
+                                      f"{lib.tc_struct_bytes(which)} in {LIB_PATH}")
         _lib = lib
     return _lib
 

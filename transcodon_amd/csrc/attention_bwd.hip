@@ -808,17 +808,11 @@ float *g_static_delta[kMaxDevices] = {};
 }  // namespace
 static __device__ __align__(256) float scratch[kStaticDeltaFloats];
 
-extern "C" int tc_attn_bwd_static(int dtype, const void *qkv, int ldq, const uint64_t *key_words, const void *out,
-                                  const void *d_out, const float *lse, void *d_qkv, int ldg, const float *rope_cos,
-                                  const float *rope_sin, float q_scale, int B, int T, int H, int D, void *stream) {
-    TC_REQUIRE(B > 0 && T > 0 && H > 0, "tc_attn_bwd_static: bad shape B=%d T=%d H=%d", B, T, H);
-    TC_REQUIRE((size_t)B * (size_t)H * (size_t)T <= kStaticDeltaFloats,
-               "tc_attn_bwd_static: B*H*T = %zu exceeds the built-in scratch of %zu floats; use tc_attn_bwd with a "
-               "caller-supplied delta buffer",
-               (size_t)B * H * T, kStaticDeltaFloats);
+// Device address of `scratch` on the current device, resolved once per device.
+static int static_delta(const char *who, float **out) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
-        tc_set_error("tc_attn_bwd_static: cannot identify the current device");
+        tc_set_error("%s: cannot identify the current device", who);
         return TC_ELAUNCH;
     }
     float *delta = __atomic_load_n(&g_static_delta[dev], __ATOMIC_ACQUIRE);
@@ -827,12 +821,32 @@ extern "C" int tc_attn_bwd_static(int dtype, const void *qkv, int ldq, const uin
         void *sym = nullptr;
         const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
         if (e != hipSuccess || !sym) {
-            tc_set_error("tc_attn_bwd_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+            tc_set_error("%s: hipGetSymbolAddress: %s", who, hipGetErrorString(e));
             return TC_ELAUNCH;
         }
         delta = static_cast<float *>(sym);
         __atomic_store_n(&g_static_delta[dev], delta, __ATOMIC_RELEASE);   // concurrent first calls store the same value
     }
+    *out = delta;
+    return TC_OK;
+}
+
+extern "C" int tc_init_device(void) {
+    float *delta = nullptr;
+    return static_delta("tc_init_device", &delta);
+}
+
+extern "C" int tc_attn_bwd_static(int dtype, const void *qkv, int ldq, const uint64_t *key_words, const void *out,
+                                  const void *d_out, const float *lse, void *d_qkv, int ldg, const float *rope_cos,
+                                  const float *rope_sin, float q_scale, int B, int T, int H, int D, void *stream) {
+    TC_REQUIRE(B > 0 && T > 0 && H > 0, "tc_attn_bwd_static: bad shape B=%d T=%d H=%d", B, T, H);
+    TC_REQUIRE((size_t)B * (size_t)H * (size_t)T <= kStaticDeltaFloats,
+               "tc_attn_bwd_static: B*H*T = %zu exceeds the built-in scratch of %zu floats; use tc_attn_bwd with a "
+               "caller-supplied delta buffer",
+               (size_t)B * H * T, kStaticDeltaFloats);
+    float *delta = nullptr;
+    const int rc = static_delta("tc_attn_bwd_static", &delta);
+    if (rc != TC_OK) return rc;
     return tc_attn_bwd(dtype, qkv, ldq, key_words, out, d_out, lse, delta, d_qkv, ldg, rope_cos, rope_sin, q_scale, B, T,
                        H, D, stream);
 }

@@ -36,6 +36,15 @@ void tc_set_error(const char *fmt, ...) {
 
 extern "C" const char *tc_last_error(void) { return g_err; }
 extern "C" int tc_version(void) { return TC_VERSION; }
+extern "C" size_t tc_struct_bytes(int which) {
+    switch (which) {
+        case 0: return sizeof(tc_layer_weights);
+        case 1: return sizeof(tc_encoder_desc);
+        case 2: return sizeof(tc_layer_grads);
+        case 3: return sizeof(tc_encoder_grads);
+        default: return 0;
+    }
+}
 
 static thread_local TcProfScope *t_scope = nullptr;
 

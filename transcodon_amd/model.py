@@ -437,8 +437,16 @@ class GraphedForward:
     launch, which is what a small batch's latency consists of.  Calling it copies the inputs into the
     graph's static buffers, replays the graph and returns the same dict as ``forward``; the tensors in
     it are the graph's own output buffers and are overwritten by the next call (clone what must live
-    longer).  Weights are read at replay time, so ``load_state_dict`` into the same parameters needs no
-    new capture; ``set_compute_dtype`` or another shape does.
+    longer).
+
+    The graph addresses the model's PACKED weights (concatenated q/k/v, compute-dtype casts, folded
+    LayerNorm products) and a workspace by raw device pointers.  It therefore keeps a reference to the
+    pack and to the workspace it was captured with (neither can be freed under it), remembers the
+    version of every parameter, and before each replay compares that with the model's current state:
+    after ``load_state_dict``, an optimiser step, ``set_compute_dtype`` or a move of the parameters the
+    graph is captured again (three eager forwards), so a replay never runs on stale or recycled
+    memory.  ``check_weights = False`` skips the comparison (about 0.1 ms of host time per call) for
+    callers that promise not to touch the weights.
 
     The kernels of a graph work in the model's workspace, so two graphs of one model may not run at the same
     time -- unless they are captured with ``private_workspace=True``: such a graph owns its workspace, and two
@@ -449,40 +457,63 @@ class GraphedForward:
         if dev.type != "cuda":
             raise _lib.HipLibraryError("GraphedForward needs the model on the GPU (there is no CPU fallback)")
         self.model, self.B, self.T = model, int(B), int(T)
+        self.device = dev
         self.tokens = torch.full((self.B, self.T), model.padding_idx, dtype=torch.int32, device=dev)
         self.tokens[:, 0] = model.cls_idx
         self.species = torch.zeros(self.B, dtype=torch.int32, device=dev)
-        repr_layers = list(repr_layers)
-        shared_ws = model._workspace
-        if private_workspace:
-            model._workspace = None                 # the calls below allocate a workspace that this graph keeps
-        try:
-            self._capture(model, dev, repr_layers)
-        finally:
-            if private_workspace:
-                self._workspace, model._workspace = model._workspace, shared_ws
+        self.repr_layers = list(repr_layers)
+        self.private_workspace = bool(private_workspace)
+        self.check_weights = True
+        self.captures = 0
+        self._workspace = None
+        self._capture()
 
-    def _capture(self, model, dev, repr_layers):
-        with torch.no_grad():
-            # first calls outside the capture: weight packing, workspace, one-time kernel attributes
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    model(self.tokens, self.species, repr_layers=repr_layers)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            self.graph = torch.cuda.CUDAGraph()
-            deferred = []
-            # thread-local capture mode: other threads of the process (a collective library's watchdog, a data
-            # loader) may call into the runtime while this thread records
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.out = model(self.tokens, self.species, repr_layers=repr_layers, _defer_status=deferred)
-            self.status = deferred[0]
+    def _weights_state(self):
+        """Cheap fingerprint of everything the captured pointers depend on."""
+        m = self.model
+        store = m._flat_store
+        if store is not None and store.data.device == self.device:
+            return ("store", m._dtype(), bool(m.fold_layernorm), store.data.data_ptr(), store.version_key())
+        return (m._dtype(), bool(m.fold_layernorm), _lib.weights_epoch[0],
+                tuple((p.data_ptr(), p._version) for p in m.parameters()))
+
+    def _capture(self):
+        model, dev = self.model, self.device
+        shared_ws = model._workspace
+        if self.private_workspace:
+            model._workspace = self._workspace      # None the first time: the calls below allocate it
+        try:
+            with torch.no_grad():
+                # first calls outside the capture: weight packing, workspace, one-time kernel attributes
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        model(self.tokens, self.species, repr_layers=self.repr_layers)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                deferred = []
+                # thread-local capture mode: other threads of the process (a collective library's watchdog, a data
+                # loader) may call into the runtime while this thread records
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    out = model(self.tokens, self.species, repr_layers=self.repr_layers, _defer_status=deferred)
+            # what the recorded kernels address: held here so that no later repack, reload or workspace
+            # regrowth of the model can hand that memory to someone else while this graph can still replay
+            self.graph, self.out, self.status = graph, out, deferred[0]
+            self._pack = model._pack
+            self._workspace = model._workspace
+            self._state = self._weights_state()
+            self.captures += 1
+        finally:
+            if self.private_workspace:
+                model._workspace = shared_ws
 
     def __call__(self, tokens, species_type_ids, check_indices=None):
         if tuple(tokens.shape) != (self.B, self.T):
             raise ValueError(f"GraphedForward was captured for tokens of shape {(self.B, self.T)}, got {tuple(tokens.shape)}")
+        if self.check_weights and self._weights_state() != self._state:
+            self._capture()                         # weights, dtype or fold changed since the capture
         self.tokens.copy_(tokens)
         self.species.copy_(species_type_ids.reshape(-1))
         self.graph.replay()

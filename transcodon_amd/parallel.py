@@ -96,6 +96,7 @@ class GradientSync:
         self.side = torch.cuda.Stream(device=store.grad.device) if store.grad.is_cuda else None
         self._pending = []
         self._staged = False          # a bucket was exchanged synchronously through the host (gloo)
+        self._backend = None          # looked up once: on_ready runs once per layer inside the backward
         self.error = None
 
     def world(self) -> int:
@@ -129,7 +130,9 @@ class GradientSync:
                 return
             b, e = self.head_range if layer < 0 else self.layer_ranges[layer]
             bucket = self.store.grad[b:e]
-            if bucket.is_cuda and dist.get_backend(self.group) == "gloo":
+            if self._backend is None:
+                self._backend = dist.get_backend(self.group)
+            if bucket.is_cuda and self._backend == "gloo":
                 # gloo (rehearsals on a box with one GPU): staged through host memory, synchronously
                 host = bucket.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
@@ -149,9 +152,13 @@ class GradientSync:
             self.error = exc
 
     def abandon(self):
-        """After a failed backward: wait for the exchanges already started (every rank issued the same
-        ones up to the failure) and forget them; the gradients of this step are not usable."""
+        """After a failed backward: wait for the exchanges already started and forget them; the gradients
+        of this step are not usable.  This only leaves the group consistent when every rank failed at the
+        same point (a shape or configuration error, which all ranks share).  A failure on ONE rank leaves
+        its peers inside all-reduces that this rank never joins: the caller must let the exception end
+        the process (the launcher then tears the group down) and not go on to another step."""
         pending, self._pending, self.error = self._pending, [], None
+        self._staged = False           # nothing of this step may be divided by the world size later
         for work in pending:
             try:
                 work.wait()

@@ -71,10 +71,10 @@ class DevicePipeline:
         for b, (r, s) in enumerate(zip(rows, structs)):
             tok[b, :len(r)] = r
             st[b, :len(s)] = s
-        struct_present = bool((st != -100).any())
+        raw_struct = bool((st != -100).any())
         dev = self.device
         tok_d, lens_d = torch.from_numpy(tok).to(dev), torch.from_numpy(lens).to(dev)
-        st_d = torch.from_numpy(st).to(dev) if struct_present else None
+        st_d = torch.from_numpy(st).to(dev) if raw_struct else None
         # 1. corruption of the whole rows (DataCollator)
         masked, labels, st_lab = mlm_mask(tok_d, lens_d, seed=(self.seed * 1000003 + int(step)) & (2 ** 63 - 1),
                                           struct_labels=st_d, mask_proportion=self.mask_proportion,
@@ -95,6 +95,10 @@ class DevicePipeline:
             inp, lens_out = crop_pad(masked, lens_d, start, T_out, self.pad_idx)
             lab, _ = crop_pad(labels, lens_d, start, T_out, -100)
             st_out = crop_pad(st_lab, lens_d, start, T_out, -100)[0] if st_lab is not None else None
+        # pretraining.py:115 asks the labels that come OUT of the pipeline: a batch whose structure labels all
+        # fell outside the drawn positions or outside the crop window has no structure term.  Only rows that
+        # carry structure labels at all pay for this device read (the shipped dataset.py:80-83 has none).
+        struct_present = bool((st_out != -100).any()) if st_out is not None else False
         if st_out is None:
             st_out = torch.full_like(lab, -100)
         organism = torch.tensor([int(it["organism"]) for it in items], dtype=torch.int64, device=dev)

@@ -126,6 +126,7 @@ class Trainer:
         self.flat.zero_grad()
         sums = torch.zeros(3, device=self.device)                          # mask loss, 2d loss, total
         any_struct = False
+        n_struct = 0                                                       # micro-batches that carried structure labels
         for a in range(A):
             items = [self.dataset[int(i)] for i in self._batch_indices(self.micro_step)]
             batch = self.pipeline.collate(items, self.micro_step * self.world + self.rank)
@@ -145,6 +146,9 @@ class Trainer:
             with torch.no_grad():
                 sums[0] += mask_loss.detach()
                 sums[2] += total.detach()
+                if batch["struct_present"]:
+                    n_struct += 1
+                    sums[1] += (total.detach() - mask_loss.detach()) / 0.4
         if self.world > 1:
             # The gradient mean covers the structure head on every rank, so every rank must take the same
             # decision about updating it: labels seen by any rank count for all (DDP hands the averaged
@@ -157,11 +161,12 @@ class Trainer:
         factor = self.lr_factor(self.global_step)
         self.opt.step(lr_factor=factor, exclude=() if any_struct else self.struct_params)
         self.global_step += 1
-        vals = (sums / A).tolist()                                         # the one host synchronisation of the step
-        rec = {"step": self.global_step, "train_mask_loss": vals[0], "lr": self.args.learning_rate * factor}
-        if any_struct:
-            rec["train_2d_mask_loss"] = (vals[2] - vals[0]) / 0.4
-            rec["train_total_loss"] = vals[2]
+        vals = sums.tolist()                                               # the one host synchronisation of the step
+        rec = {"step": self.global_step, "train_mask_loss": vals[0] / A, "lr": self.args.learning_rate * factor}
+        if n_struct:
+            # the reference logs the 2d term per batch that has labels (pretraining.py:128): mean over those
+            rec["train_2d_mask_loss"] = vals[1] / n_struct
+            rec["train_total_loss"] = vals[2] / A
         return rec
 
     def validate(self):
