@@ -6,8 +6,10 @@ Stated tolerances
   f32 path : |dlogit| <= 2e-4 absolute (accumulation order differs from the CPU BLAS);
              decoded codons identical wherever the oracle's decision margin
              (log p_best - log p_second) exceeds 1e-3.
-  bf16 path: |dlogit| <= 0.08 absolute and <= 0.02 RMS on logits of O(1) spread
-             (bf16 operands, fp32 accumulation / softmax / LayerNorm / residual).
+  bf16 path: |dlogit| <= 0.06 absolute and <= 0.015 RMS on logits of O(1) spread
+             (bf16 operands, fp32 accumulation / softmax / LayerNorm / residual): three times the
+             largest values measured over the tests of this file (2.2e-2 and 5.4e-3, printed by
+             every check), so that a regression of the kernels' accuracy shows.
 """
 import json
 import os
@@ -23,7 +25,7 @@ from oracle.weights import seeded_state_dict
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 F32_ATOL = 2e-4
-BF16_ATOL, BF16_RMS = 0.08, 0.02
+BF16_ATOL, BF16_RMS = 0.06, 0.015
 MARGIN = 1e-3
 
 
@@ -56,6 +58,7 @@ def _check(out, want, keep, dtype):
     if dtype == torch.float32:
         assert float(np.abs(d).max()) <= F32_ATOL, float(np.abs(d).max())
     else:
+        print(f"  [bf16 logit error: max {float(np.abs(d).max()):.3e} rms {float(np.sqrt((d ** 2).mean())):.3e}]")
         assert float(np.abs(d).max()) <= BF16_ATOL, float(np.abs(d).max())
         assert float(np.sqrt((d ** 2).mean())) <= BF16_RMS
 
@@ -184,7 +187,8 @@ def test_full_row5_bf16_logits(golden_dir, full_bf16):
     agree = np.mean([rna[3 * i:3 * i + 3] == rna_ref[3 * i:3 * i + 3] for i in range(len(aa))])
     confident = [i for i in range(len(aa)) if g["margins"][i] > 0.1]
     assert all(rna[3 * i:3 * i + 3] == rna_ref[3 * i:3 * i + 3] for i in confident)
-    assert agree > 0.9
+    print(f"  [bf16 codon agreement {agree:.4f}]")
+    assert agree >= 0.98                  # measured: 1.0
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

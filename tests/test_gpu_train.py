@@ -224,7 +224,8 @@ def test_full_config_gradients_match_oracle_autograd(dtype):
     loss.backward()
     assert abs(float(loss) - ref_loss) <= (2e-4 if dtype == torch.float32 else 3e-2), (float(loss), ref_loss)
     got = dict(m.named_parameters())
-    tol = 5e-4 if dtype == torch.float32 else 8e-2
+    tol = 5e-4 if dtype == torch.float32 else 3.5e-2          # bf16 measured: 1.1e-2
+    seen = {"qk_cos": 1.0, "err": 0.0, "cos": 1.0}
     for k, r in ref.items():
         if k == "lm_head.weight":
             continue
@@ -232,17 +233,23 @@ def test_full_config_gradients_match_oracle_autograd(dtype):
         scale = max(float(r.abs().max()), 1e-8)
         err = float((g - r).abs().max()) / scale
         cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-30)) if r.numel() > 16 else 1.0
+        if ".q_proj." in k or ".k_proj." in k:
+            seen["qk_cos"] = min(seen["qk_cos"], cos)
+        else:
+            seen["err"], seen["cos"] = max(seen["err"], err), min(seen["cos"], cos)
         # With freshly initialised weights attention is nearly uniform, so the q/k projection
         # gradients are differences of almost equal terms (dS = P (dP - delta)) three orders of
         # magnitude below the other gradients: in bf16 they are rounding-dominated (cosine
         # 0.90-0.99 against the fp32 oracle), exact in the f32 path.
         cancelling = dtype == torch.bfloat16 and (".q_proj." in k or ".k_proj." in k)
         if cancelling:
-            assert cos >= 0.85, (k, cos)
+            assert cos >= 0.87, (k, cos)                     # measured: 0.895
         else:
             assert err <= tol, (k, err)
             if dtype == torch.bfloat16:
-                assert cos >= 0.99, (k, cos)
+                assert cos >= 0.9995, (k, cos)               # measured: 0.99996
+    print(f"  [{dtype}: worst relative gradient error {seen['err']:.3e}, worst cosine {seen['cos']:.5f}, "
+          f"worst q/k projection cosine {seen['qk_cos']:.4f}]")
 
 
 def test_full_config_bf16_query_key_gradients_with_peaked_attention():
