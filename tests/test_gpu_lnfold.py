@@ -93,37 +93,56 @@ def test_residual_product_writes_copy_and_row_sums():
     np.testing.assert_allclose(rows[:, 1].cpu().numpy(), (-rstd * mean).cpu().numpy(), rtol=2e-5, atol=1e-6)
 
 
-def test_residual_product_on_split_planes():
+@pytest.mark.parametrize("Mr,K", [(M, 768), (M, 3072), (M, 256), (30 * 1024 + 700, 768)])
+def test_residual_product_on_split_planes(Mr, K):
     """x = hi + lo (two bf16 planes) updated in place by tc_gemm_residual_split: the new pair represents
     the f32 result of the plain residual product on the same x to 16 bits of mantissa, hi is its bf16
-    rounding exactly, and the row sums are those of the new hi plane."""
+    rounding, and the row sums are those of the new hi plane.  With fewer than eight k-tiles (K = 256) the
+    kernel starts its accumulators at residual + bias like the plain product and hi is that product's
+    rounding bit for bit; from eight k-tiles on the planes are added under the k-loop and the bias at the
+    end, so the f32 sum is rounded in another order: hi then differs from the plain product's rounding at
+    rounding ties only (stated: fewer than one element in 500, by one bf16 step) and the pair stays within
+    2^-15.  The last case has a row tail in its last tile (rows past M read as zero and are not stored)."""
     lib = _lib.load()
     g = torch.Generator().manual_seed(6)
-    a = torch.randn(M, E, generator=g).to(DEV, torch.bfloat16)
-    w = (torch.randn(E, E, generator=g) * 0.03).to(DEV, torch.bfloat16)
+    a = torch.randn(Mr, K, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(E, K, generator=g) * 0.03).to(DEV, torch.bfloat16)
     bias = (0.1 * torch.randn(E, generator=g)).to(DEV)
-    x = (torch.randn(M, E, generator=g) * 3 + 1.0).to(DEV)
+    x = (torch.randn(Mr, E, generator=g) * 3 + 1.0).to(DEV)
     hi = x.to(torch.bfloat16)
     lo = (x - hi.float()).to(torch.bfloat16)
     x16 = hi.float() + lo.float()                                     # what the planes hold
     want = ops.gemm(a, w, bias, epilogue=_lib.EPI_BIAS_RESIDUAL, residual=x16)
-    acc = torch.zeros(M, 2, dtype=torch.int64, device=DEV)
-    _lib.check(lib.tc_gemm_residual_split(_lib.TC_BF16, a.data_ptr(), E, w.data_ptr(), bias.data_ptr(), hi.data_ptr(),
-                                          lo.data_ptr(), acc.data_ptr(), E, M, E, E, _stream()), "tc_gemm_residual_split")
-    assert torch.equal(hi, want.to(torch.bfloat16))
+    acc = torch.zeros(Mr, 2, dtype=torch.int64, device=DEV)
+    _lib.check(lib.tc_gemm_residual_split(_lib.TC_BF16, a.data_ptr(), K, w.data_ptr(), bias.data_ptr(), hi.data_ptr(),
+                                          lo.data_ptr(), acc.data_ptr(), E, Mr, E, K, _stream()), "tc_gemm_residual_split")
+    want16 = want.to(torch.bfloat16)
+    if K < 512:
+        assert torch.equal(hi, want16)
+    else:
+        differ = hi != want16
+        frac = float(differ.float().mean())
+        step = (hi.float() - want16.float()).abs() / want.abs().clamp_min(1e-3)
+        print(f"  [streamed residual, K={K}, M={Mr}: {frac:.2e} of the hi plane differs from the plain product's rounding, "
+              f"largest step {float(step.max()):.3g}]")
+        assert frac < 2e-3 and float(step.max()) <= 2.0 ** -7
     got = hi.float() + lo.float()
-    rel = ((got - want).abs() / want.abs().clamp_min(1e-3)).max()
-    assert float(rel) <= 2.0 ** -15, float(rel)
+    # 16 bits of mantissa for the pair; the streamed form also rounds its f32 partial sums (terms of size 1 to 16)
+    # in another order than the plain product: stated 2^-16 absolute on top (2^-20 of the largest terms; measured 4.3e-6)
+    err = (got - want).abs()
+    over = err - 2.0 ** -15 * want.abs()
+    print(f"  [pair against the plain f32 product: largest |error| {float(err.max()):.3g}, beyond 2^-15 |value| {float(over.max()):.3g}]")
+    assert float(over.max()) <= (2.0 ** -16 if K >= 512 else 2.0 ** -15 * 1e-3)
     s1 = acc[:, 0].double() / 2 ** 24
     np.testing.assert_allclose(s1.cpu().numpy(), hi.double().sum(1).cpu().numpy(), rtol=0, atol=2e-3)
-    out = torch.empty(M, E, device=DEV)
-    _lib.check(lib.tc_split_to_f32(hi.data_ptr(), lo.data_ptr(), out.data_ptr(), M * E, _stream()), "tc_split_to_f32")
+    out = torch.empty(Mr, E, device=DEV)
+    _lib.check(lib.tc_split_to_f32(hi.data_ptr(), lo.data_ptr(), out.data_ptr(), Mr * E, _stream()), "tc_split_to_f32")
     assert torch.equal(out, got)
     gamma = (1 + 0.1 * torch.randn(E, generator=g)).to(DEV)
     beta = (0.1 * torch.randn(E, generator=g)).to(DEV)
-    ln = torch.empty(M, E, device=DEV)
+    ln = torch.empty(Mr, E, device=DEV)
     _lib.check(lib.tc_layernorm_fwd_split(hi.data_ptr(), lo.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ln.data_ptr(),
-                                          None, M, E, 1e-5, _stream()), "tc_layernorm_fwd_split")
+                                          None, Mr, E, 1e-5, _stream()), "tc_layernorm_fwd_split")
     assert torch.equal(ln, ops.layernorm(got, gamma, beta, 1e-5))
 
 

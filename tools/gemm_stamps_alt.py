@@ -9,7 +9,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtc_stamps.so"))
+lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("TC_STAMPS_LIB", "libtc_stamps.so")))
 vp = C.c_void_p
 lib.tc_gemm.restype = C.c_int
 lib.tc_gemm.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -18,6 +18,8 @@ lib.tc_debug_set_stamp_buffer.argtypes = [vp]
 lib.tc_last_error.restype = C.c_char_p
 lib.tc_gemm_train.restype = C.c_int
 lib.tc_gemm_train.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+lib.tc_gemm_residual_split.restype = C.c_int
+lib.tc_gemm_residual_split.argtypes = [C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
 
 dev = "cuda"
 M, E, F, T = 131072, 768, 3072, 512
@@ -31,18 +33,26 @@ stamps = torch.zeros(256 * 2 * 32 + 256 * 2 * 26, dtype=torch.int64, device=dev)
 lib.tc_debug_set_stamp_buffer(stamps.data_ptr())
 SHAPES = {"bias": (x, F, E, 0), "fc1": (x, F, E, 1), "qkv": (x, 3 * E, E, 3), "out": (x, E, E, 2),
           "out_f32": (x, E, E, 4), "out_bf16": (x, E, E, 0),
-          "fc2": (mid, E, F, 2), "fc2_f32": (mid, E, F, 4), "fc2_bf16": (mid, E, F, 0)}
+          "fc2": (mid, E, F, 2), "fc2_f32": (mid, E, F, 4), "fc2_bf16": (mid, E, F, 0),
+          # residual stream as two bf16 planes updated in place (TC_RES_STREAM=0: accumulators preloaded)
+          "out_split": (x, E, E, 5), "fc2_split": (mid, E, F, 5)}
+plane_hi = torch.randn(M, E, device=dev, generator=g).bfloat16()
+plane_lo = (torch.randn(M, E, device=dev, generator=g) * 1e-3).bfloat16()
+row_acc = torch.zeros(M, 2, device=dev, dtype=torch.int64)
 names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["bias", "fc1", "qkv", "out"]
 for name in names:
     a, N, K, epi = SHAPES[name]
     w = (torch.randn(N, K, device=dev, generator=g) * 0.03).bfloat16()
     b = torch.randn(N, device=dev, generator=g) * 0.1
     ldo = N + 64 if N == F else N      # rows of 6144 bytes store slowly: pad them
-    out = torch.empty(M, ldo, device=dev, dtype=torch.float32 if epi in (2, 4) else torch.bfloat16)
+    out = torch.empty(M, ldo, device=dev, dtype=torch.float32 if epi in (2, 4, 5) else torch.bfloat16)
     s = torch.cuda.current_stream().cuda_stream
     for it in range(3):
         stamps.zero_()
-        if epi == 4:
+        if epi == 5:
+            rc = lib.tc_gemm_residual_split(1, a.data_ptr(), a.shape[1], w.data_ptr(), b.data_ptr(), plane_hi.data_ptr(), plane_lo.data_ptr(),
+                                            row_acc.data_ptr(), ldo, M, N, K, s)
+        elif epi == 4:
             rc = lib.tc_gemm_train(1, 4, a.data_ptr(), a.shape[1], w.data_ptr(), None, None, out.data_ptr(), None, ldo, M, N, K, 1, s)
         else:
             rc = lib.tc_gemm(1, epi, a.data_ptr(), a.shape[1], w.data_ptr(), None if epi == 4 else b.data_ptr(), res.data_ptr() if epi == 2 else None,

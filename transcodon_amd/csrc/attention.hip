@@ -329,7 +329,10 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attn_bf16_kernel(const AttnPar
                 }
             const float ls = lsum0 + lsum1;
             l_run += ls;
-            danger |= !(ls < 1099511627776.0f);                         // 2^40, or a NaN
+            // ls >= 2^40, +inf or NaN, tested on the bit pattern: a sum of non-negative terms orders like its
+            // unsigned image, every NaN lies above +inf there, and no floating-point compare is involved that
+            // the file's no-NaN arithmetic flags could rewrite (a sign bit, which cannot occur, also counts)
+            danger |= __builtin_bit_cast(uint32_t, ls) >= 0x53800000u;
         } else {
             const float tmax = tile_max() * kLog2e;
             const float m_new = (tmax > m_run + kLazy) ? tmax : m_run;     // m_run = -inf: the first valid tile sets it

@@ -1095,14 +1095,71 @@ constexpr int LDS_BYTES = ROWS_OFF + 2 * 1024;  // 158 KiB
 // t & 1), converts the four column waves' f32 partials to integers in units of 2^-24 (an exact image
 // of each) and adds their sum with one 64-bit atomic.  Integer adds: the result does not depend on
 // the order in which the column tiles of a row arrive.
+template <bool kFresh = false>
 __device__ __forceinline__ void flush_row_sums(const GemmParams &p, const char *planes, int tm) {
-    const int t = threadIdx.x, row = t >> 1, which = t & 1;
+    int t = threadIdx.x;
+    unsigned long long *acc_base = p.row_acc;
+    if constexpr (kFresh) {
+        // called from inside a k-loop whose registers are all taken: the thread index and the accumulator
+        // address are made here, from the lane counter and from scalar registers, instead of living through
+        // the loop (where they were spilled, and every reload waited for the staging loads in flight)
+        t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 64 + __builtin_amdgcn_mbcnt_hi(-1, __builtin_amdgcn_mbcnt_lo(-1, 0));
+        asm volatile("" : "+v"(t));
+        asm volatile("" : "+s"(acc_base));
+    }
+    const int row = t >> 1, which = t & 1;
     long long sum = 0;
 #pragma unroll
     for (int pl = 0; pl < 4; ++pl)
         sum += (long long)(*reinterpret_cast<const float *>(planes + (pl * 256 + row) * 8 + which * 4) * 16777216.f);
-    if (tm * 256 + row < p.M) atomicAdd(p.row_acc + 2L * (tm * 256 + row) + which, (unsigned long long)sum);
+    if (tm * 256 + row < p.M) atomicAdd(acc_base + 2L * (tm * 256 + row) + which, (unsigned long long)sum);
 }
+
+// Residual tile streamed in during the k-loop (gemm256x_kernel<bf16, TC_EPI_BIAS_RESIDUAL, FOLD>).
+// A 16-byte piece per lane comes straight into registers through a BOUNDED raw buffer descriptor (rows
+// past the end of the plane read as zero, so a tile's row tail needs no clamping) by an assembly load:
+// the compiler neither counts it nor waits for it -- the k-tile's one counted vmcnt wait covers it, because
+// the loads are issued before that k-tile's first staging piece and the counter retires in issue order.
+__device__ __forceinline__ u32x4 tc_raw_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    // (readfirstlane: the words must be provably wave-uniform to sit in the scalar registers the load takes them from)
+    return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)),
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+}
+__device__ __forceinline__ u32x4 tc_buf_load16_async(u32x4 rsrc, unsigned lane_off, unsigned uniform_off) {
+    u32x4 v;
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)uniform_off);
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(lane_off), "s"(rsrc), "s"(soff));
+    return v;
+}
+// The same load into a NAMED register quadruple, and the matrix instruction that later reads it by name.  A value
+// that is still on its way from memory when the compiler sees it "defined" must never be moved: with the
+// register fixed at both ends there is no copy to insert.  Slot s = v[128 + 4 s .. 131 + 4 s].
+template <int SLOT>
+__device__ __forceinline__ void tc_buf_load16_slot(u32x4 &v, u32x4 rsrc, unsigned lane_off, unsigned uniform_off) {
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)uniform_off);
+#define TC_SLOT_LOAD(S, R)                                                                                              \
+    if constexpr (SLOT == S)                                                                                            \
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "={" R "}"(v) : "v"(lane_off), "s"(rsrc), "s"(soff))
+    TC_SLOT_LOAD(0, "v[128:131]"); TC_SLOT_LOAD(1, "v[132:135]"); TC_SLOT_LOAD(2, "v[136:139]"); TC_SLOT_LOAD(3, "v[140:143]");
+    TC_SLOT_LOAD(4, "v[144:147]"); TC_SLOT_LOAD(5, "v[148:151]"); TC_SLOT_LOAD(6, "v[152:155]"); TC_SLOT_LOAD(7, "v[156:159]");
+#undef TC_SLOT_LOAD
+}
+template <int SLOT>
+__device__ __forceinline__ void tc_mfma_bf16_slot(f32x4 &d, const f32x4 &sel, const u32x4 &v) {
+#define TC_SLOT_MFMA(S, R)                                                                                              \
+    if constexpr (SLOT == S) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(sel), "{" R "}"(v))
+    TC_SLOT_MFMA(0, "v[128:131]"); TC_SLOT_MFMA(1, "v[132:135]"); TC_SLOT_MFMA(2, "v[136:139]"); TC_SLOT_MFMA(3, "v[140:143]");
+    TC_SLOT_MFMA(4, "v[144:147]"); TC_SLOT_MFMA(5, "v[148:151]"); TC_SLOT_MFMA(6, "v[152:155]"); TC_SLOT_MFMA(7, "v[156:159]");
+#undef TC_SLOT_MFMA
+}
+#ifndef TC_RES_STREAM_DEFAULT
+#define TC_RES_STREAM_DEFAULT 1
+#endif
+// A tile's residual is 32 plane pieces (16 pieces of 16 rows x 32 columns per lane group, hi and lo plane each);
+// STREAM of them are requested per k-tile during the tile's first ceil(32 / STREAM) k-tiles.
+constexpr int res_stream_tiles(int per_ktile) { return (32 + per_ktile - 1) / per_ktile; }
 
 constexpr bool piecewise_epilogue(int epi) {
     return epi == TC_EPI_BIAS || epi == TC_EPI_BIAS_GELU || epi == TC_EPI_BIAS_GELU_SAVE ||
@@ -1124,8 +1181,10 @@ constexpr bool piecewise_epilogue(int epi) {
 #define TC_GEMM_EARLY 0
 #endif
 
-template <typename T, int EPI, bool FOLD = false, bool PANELS = false>
+template <typename T, int EPI, bool FOLD = false, bool PANELS = false, int STREAM = 0>
 __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
+    static_assert(!STREAM || (FOLD && EPI == TC_EPI_BIAS_RESIDUAL && !PANELS), "streamed residual: the product on bf16 planes only");
+    static_assert(STREAM == 0 || STREAM == 2 || STREAM == 3, "plane pieces per k-tile");
     using namespace k256x;
     static_assert(!PANELS || (EPI == TC_EPI_QKV_ROPE && FOLD), "row panel lists: folded q/k/v product only");
     constexpr int kEarly = TC_GEMM_EARLY;      // MFMAs of a phase issued after its hand-over barrier
@@ -1133,12 +1192,16 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     // Epilogues that read nothing from global memory (bias comes through LDS) run inside phase 0
     // of the next tile's first k-tile, after that phase's LDS-DMA issue and before its LDS reads:
     // nothing then waits for their stores.  The others run as one block between two tiles.
-    constexpr bool kPiece = piecewise_epilogue(EPI);
+    // The residual product on bf16 planes has a deferred epilogue as well: its residual tile does not start
+    // the accumulators but is added to them during the tile's first k-tiles, STREAM plane pieces per k-tile.
+    constexpr bool kStream = STREAM > 0;
+    constexpr bool kXchg = STREAM >= 3;          // residual requests coalesced by rows, lane exchange before use
+    constexpr bool kPiece = piecewise_epilogue(EPI) || kStream;
     // bf16 results use the interleaved column order (16-byte stores); so does the f32 residual result
     // (two 16-byte stores side by side: 128 contiguous bytes per row, and its optional bf16 copy is one
     // 16-byte store); the plain f32 result keeps the plain order
     constexpr int kLay = EPI == TC_EPI_PLAIN_F32 ? 1 : 2;
-    constexpr int kTileStores = EPI == TC_EPI_BIAS_GELU_SAVE ? 32 : (kLay == 2 ? 16 : 32);   // store instructions per wave
+    constexpr int kTileStores = (EPI == TC_EPI_BIAS_GELU_SAVE || kStream) ? 32 : (kLay == 2 ? 16 : 32);   // store instructions per wave
     constexpr bool kGeluTable = EPI == TC_EPI_BIAS_GELU || EPI == TC_EPI_BIAS_GELU_SAVE;
     static_assert(kPhiEntries * 4 <= STEP_OFF - ROPE_OFF, "the Phi table takes the place of the rotary slices");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1195,17 +1258,29 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     const int schunk = (lane & 7) ^ srow;
     unsigned a1_src[2];                          // cursor 1 (k-tile g+1): A1
     unsigned b0_src[2], a0_src[2], b1_src[2];    // cursor 2 (k-tile g+2): B0, A0, B1
+    // (with a streamed residual the lane's row and chunk are made afresh from the lane counter where a cursor
+    // moves to its next tile, once per tile, instead of occupying registers through the k-loop)
+    auto fresh_lane = [&]() -> int {
+        int L = lane;
+        if constexpr (kStream) {
+            L = __builtin_amdgcn_mbcnt_hi(-1, __builtin_amdgcn_mbcnt_lo(-1, 0));
+            asm volatile("" : "+v"(L));
+        }
+        return L;
+    };
     auto a_src_of = [&](int tm, int h, int i) -> unsigned {
         int row0 = tm * BM, lim = p.M;
         if constexpr (PANELS) { row0 = p.panels[4 * tm]; lim = p.panels[4 * tm + 1]; }
-        int gm = row0 + h * 128 + (wid * 2 + i) * 8 + srow;
+        const int L = fresh_lane(), srow_ = kStream ? L >> 3 : srow, schunk_ = kStream ? (L & 7) ^ srow_ : schunk;
+        int gm = row0 + h * 128 + (wid * 2 + i) * 8 + srow_;
         gm = gm < lim ? gm : lim - 1;
-        return (unsigned)gm * (unsigned)p.lda_bytes + schunk * 16;
+        return (unsigned)gm * (unsigned)p.lda_bytes + schunk_ * 16;
     };
     auto b_src_of = [&](int tn, int h, int i) -> unsigned {
         // row (2 wid + i) * 8 + srow of the half-tile: bit 3 of the row is i
-        const int chunk = kLay == 2 ? (lane & 7) ^ ((srow & 3) | (i << 2)) : schunk;
-        return (unsigned)(tn * BN + h * 128 + (wid * 2 + i) * 8 + srow) * (unsigned)p.ldw_bytes + chunk * 16;
+        const int L = fresh_lane(), srow_ = kStream ? L >> 3 : srow, schunk_ = kStream ? (L & 7) ^ srow_ : schunk;
+        const int chunk = kLay == 2 ? (L & 7) ^ ((srow_ & 3) | (i << 2)) : schunk_;
+        return (unsigned)(tn * BN + h * 128 + (wid * 2 + i) * 8 + srow_) * (unsigned)p.ldw_bytes + chunk * 16;
     };
     int c1m = tm0, c1n = tn0, c2m = tm0, c2n = tn0;      // tiles of the two staging cursors
     int c1i = tile0, c2i = tile0, ti = tile0;            // ... and their linear indices (and the math cursor's)
@@ -1290,6 +1365,43 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         }
     };
 
+    // ---- streamed residual: plane descriptors, the lane's offset inside a tile, selection fragments ----
+    // Piece (nq, mi) of a tile is 16 rows x 32 columns of a plane: lane (frow, fgrp) holds row frow, columns
+    // 8 fgrp .. + 7, i.e. the B operand of mfma_f32_16x16x32_bf16 with k = column inside the 32-column block.
+    // Multiplied by a 0/1 selection fragment S_nb (S_nb[i][k] = 1 where column k is operand row i of
+    // accumulator tile nb: k = (i >> 2) * 8 + nb * 4 + (i & 3)) it adds the plane's values to the accumulator
+    // pair of that block exactly (1.0 x bf16 products, f32 accumulation): the matrix unit does the residual
+    // add, no conversion or vector add exists, and the loaded registers are MFMA operands as they stand.
+    u32x4 rsrc_hi = {0u, 0u, 0u, 0u}, rsrc_lo = {0u, 0u, 0u, 0u};
+    unsigned res_voff = 0;
+    char *const ident_slot = smem + ROWS_OFF;     // S_0, S_1: 1 KiB each (the row-statistics slot is free here)
+    if constexpr (kStream) {
+        const unsigned plane_bytes = (unsigned)p.M * (unsigned)p.ldo * 2u;
+        rsrc_hi = tc_raw_rsrc(p.residual, plane_bytes);
+        rsrc_lo = tc_raw_rsrc(p.res_lo, plane_bytes);
+        // coalesced: four neighbouring lanes read the 64 contiguous bytes of one row (lane L: row L >> 2, chunk L & 3);
+        // a lane exchange after the wait brings them into the operand order (row frow, chunk fgrp).  Requests whose
+        // sixteen neighbouring lanes go to sixteen different rows cost the memory pipeline about four times as much.
+        // (kept for the short k-loops only, STREAM >= 3, where the memory pipeline is the bound: -2 % there; the long
+        // ones sit on the LDS port, which the exchange uses too, and read in operand order: lane = frow + 16 fgrp)
+        res_voff = kXchg ? (unsigned)((wr * 64 + (lane >> 2)) * p.ldo + wc * 32 + (lane & 3) * 8) * 2u
+                         : (unsigned)((wr * 64 + frow) * p.ldo + wc * 32 + fgrp * 8) * 2u;
+        if (wid == 0) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                u32x4 w = {0u, 0u, 0u, 0u};
+                const int kk = nb * 4 + (frow & 3);
+                const unsigned one = (kk & 1) ? 0x3F800000u : 0x00003F80u;
+                if (fgrp == (frow >> 2)) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = e == (kk >> 1) ? one : 0u;
+                }
+                *reinterpret_cast<u32x4 *>(ident_slot + nb * 1024 + lane * 16) = w;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+
     int a_off[2], b_off[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -1341,6 +1453,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     }
 
     f32x4 acc[4][8];                              // [ni][mi], D[n][m]
+    u32x4 rq[2][4] = {};                          // streamed residual: two register sets of plane pieces in flight
     if constexpr (kPiece) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
@@ -1373,9 +1486,15 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     using I1 = std::integral_constant<int, 1>;
     constexpr bool kQuarters = kPiece && TC_GEMM_PIECES && EPI != TC_EPI_BIAS_GELU_SAVE;
     // epilogue of tile `local` (bias from this wave's LDS copy), accumulators back to zero
-    auto finish_tile = [&](int tm, int tn) {
+    auto finish_tile = [&](int tm, int tn, int parity) __attribute__((always_inline)) {
         const int mrow0 = tm * BM + wr * 64 + frow, ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);
-        if constexpr (PANELS) {
+        if constexpr (kStream) {
+            // bias from the wave's LDS slot, the result as bf16 hi / lo planes, row sums of the hi plane into
+            // the plane set of this tile's parity (flushed one k-tile later, behind that k-tile's barriers)
+            epilogue256<T, EPI, kLay, 0, 8, 0, 4, false, true>(
+                p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, lds_bias ? bias_slot : nullptr, nullptr, nullptr, nullptr,
+                p.row_acc ? smem + ROPE_OFF + parity * 8192 : nullptr);
+        } else if constexpr (PANELS) {
             // the epilogue addresses row 256 tm + r of `out` and keeps rows below M: shift both to the panel
             GemmParams q = p;
             const int shift = p.panels[4 * tm] - tm * BM;
@@ -1427,20 +1546,60 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         bool prev_full = kPiece && t > 0 && ptm * BM + BM <= p.M;
         if constexpr (PANELS) prev_full = t > 0 && p.panels[4 * ptm + 1] - p.panels[4 * ptm] == BM;
 
-        for (int kt = 0; kt < p.nk; ++kt, ++g) {
+        // The unrolled k-tiles of the streamed form name the accumulators in fixed registers at every k-tile
+        // boundary: without that the register allocator renames them from copy to copy of the body and pays
+        // for it with moves and spills inside the loop.
+        auto pin_acc = [&]() __attribute__((always_inline)) {
+            asm volatile("" : "+{v[0:3]}"(acc[0][0]), "+{v[4:7]}"(acc[0][1]), "+{v[8:11]}"(acc[0][2]), "+{v[12:15]}"(acc[0][3]), "+{v[16:19]}"(acc[0][4]), "+{v[20:23]}"(acc[0][5]), "+{v[24:27]}"(acc[0][6]), "+{v[28:31]}"(acc[0][7]));
+            asm volatile("" : "+{v[32:35]}"(acc[1][0]), "+{v[36:39]}"(acc[1][1]), "+{v[40:43]}"(acc[1][2]), "+{v[44:47]}"(acc[1][3]), "+{v[48:51]}"(acc[1][4]), "+{v[52:55]}"(acc[1][5]), "+{v[56:59]}"(acc[1][6]), "+{v[60:63]}"(acc[1][7]));
+            asm volatile("" : "+{v[64:67]}"(acc[2][0]), "+{v[68:71]}"(acc[2][1]), "+{v[72:75]}"(acc[2][2]), "+{v[76:79]}"(acc[2][3]), "+{v[80:83]}"(acc[2][4]), "+{v[84:87]}"(acc[2][5]), "+{v[88:91]}"(acc[2][6]), "+{v[92:95]}"(acc[2][7]));
+            asm volatile("" : "+{v[96:99]}"(acc[3][0]), "+{v[100:103]}"(acc[3][1]), "+{v[104:107]}"(acc[3][2]), "+{v[108:111]}"(acc[3][3]), "+{v[112:115]}"(acc[3][4]), "+{v[116:119]}"(acc[3][5]), "+{v[120:123]}"(acc[3][6]), "+{v[124:127]}"(acc[3][7]));
+        };
+        // One k-tile.  J >= 0 (kStream): the J-th of a tile's first res_stream_tiles(STREAM) k-tiles, instantiated once
+        // each so that the two residual pieces it adds name their accumulators statically; J = -1: any other.
+        auto ktile = [&](const int kt, auto jc) __attribute__((always_inline)) {
+            constexpr int J = decltype(jc)::value;
+            if constexpr (kStream) pin_acc();
             const int cur = (g & 1) * DBUF_BYTES, nxt = DBUF_BYTES - cur;
             const char *sb = smem + cur;
-            const bool after = kPiece && kt == 0 && t > 0;   // the epilogue of tile t-1 is pending
+            // the epilogue of tile t-1 is pending (with a streamed residual only instance J = 0 is ever a first k-tile)
+            const bool after = kPiece && (!kStream || J == 0) && kt == 0 && t > 0;
             TC_STAMP(s0);
             f32x4 bq[2][2][2];                   // [nq][column block][k-step]
             f32x4 af[4][2];                      // [row block][k-step] of the current mq
+            // Streamed residual.  Instance J < kU requests plane pieces STREAM J .. STREAM J + STREAM - 1 of this tile
+            // (plane piece q: column half q >> 4, row block (q >> 1) & 7, plane q & 1; 16 bytes per lane) in its
+            // phase 3, into register set J & 1; the counted wait of that phase leaves them in flight with the three
+            // half-tiles issued after this k-tile's A1, and the wait of the NEXT k-tile (instance J + 1) covers
+            // them: one k-tile of lead.  Instance J + 1 multiplies them into their accumulator pairs at the start
+            // of its phase 3 MFMA turn.
+            constexpr int JJ = J < 0 ? 0 : J;
+            constexpr int kU = kStream ? res_stream_tiles(STREAM ? STREAM : 1) : 0;
+            constexpr int kIssued = (kStream && J >= 0 && J < kU) ? (32 - JJ * STREAM < STREAM ? 32 - JJ * STREAM : STREAM) : 0;
+            auto res_issue = [&](auto uc) __attribute__((always_inline)) {
+                constexpr int u = decltype(uc)::value, q = JJ * STREAM + u;
+                if constexpr (u < kIssued) {
+                    constexpr int nq = q >> 4, mi = (q >> 1) & 7;
+                    const unsigned off = ((unsigned)(tm * BM + mi_off<2>(mi)) * (unsigned)p.ldo + (unsigned)(tn * BN + nq * 128)) * 2u;
+#ifdef TC_ABL_RESLDS
+                    // measurement build: the same bytes by LDS-DMA into a dump area (no register return; results are garbage)
+                    tc_blds16(tc_buffer_rsrc((q & 1) ? p.res_lo : reinterpret_cast<const char *>(p.residual)), res_voff, off,
+                              smem + STEP_OFF + (wid & 3) * 1024);
+#elif defined(TC_ABL_RESL2)
+                    // measurement build: every request of the kernel reads the plane's first 16 x 256 block (cache hits)
+                    tc_buf_load16_slot<(JJ & 1) * 4 + u>(rq[JJ & 1][u], (q & 1) ? rsrc_lo : rsrc_hi, res_voff, 0u * off);
+#else
+                    tc_buf_load16_slot<(JJ & 1) * 4 + u>(rq[JJ & 1][u], (q & 1) ? rsrc_lo : rsrc_hi, res_voff, off);
+#endif
+                }
+            };
 
             // A phase's 16 MFMAs, then the barrier that hands the matrix pipe to the other wave of the SIMD.
             // TC_GEMM_EARLY = n enters that barrier n MFMAs before the end of the turn.  On bare MFMA turns that
             // removes the wake-up gap of the released wave (tools/ubench/mfma_handover.hip: 256 -> 217 ns per 32
             // MFMAs); here it costs 3-9 %, because the phase is bound by the load slot of the wave that is not
             // multiplying, and the late MFMAs delay the start of that slot.
-            auto math = [&](int mq, int nq) {
+            auto math = [&](int mq, int nq, bool hand_over = true) {
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
@@ -1454,7 +1613,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
                                 acc[nq * 2 + nb][mq * 4 + i], 0, 0, 0);
                         }
                 __builtin_amdgcn_s_setprio(0);
-                if (kEarly == 0) TC_XBAR();
+                if (kEarly == 0 && hand_over) TC_XBAR();
             };
             auto read_b = [&](int nq) {
 #pragma unroll
@@ -1490,6 +1649,11 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             // ---- phase 0 ----
             TC_PH_START();
             if (kPiece && kt == 1) stage_epilogue_inputs(tm, tn);
+            if constexpr (kStream) {
+                // row sums of the tile before: its epilogue ran one k-tile ago, the barriers since then have
+                // published every wave's plane entries (an atomic per thread, older than this k-tile's A1)
+                if (kt == 1 && t > 0 && p.row_acc) flush_row_sums<true>(p, smem + ROPE_OFF + ((t - 1) & 1) * 8192, ptm);
+            }
             if (c1_tile < my_count) {
                 stage_half(nxt + SLOT_A1, p.A, a1_src, (unsigned)c1_k * 128u);
                 if (++c1_k == p.nk) { c1_k = 0; if (++c1_tile < my_count) { advance(c1m, c1n, c1i); set_c1(); } }
@@ -1499,7 +1663,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             } else if constexpr (kPiece) {
                 if (after) {
                     TC_STAMP(e0);
-                    finish_tile(ptm, ptn);
+                    finish_tile(ptm, ptn, (t - 1) & 1);
                     __builtin_amdgcn_sched_barrier(0);
 #ifdef TC_GEMM_STAMPS
                     TC_STAMP(e1);
@@ -1552,14 +1716,31 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
                 if (after && more) stage_half(cur + SLOT_B1, p.W, b1_src, koff2);
                 if (after) finish_quarter(ptm, ptn, I1{}, I0{});
             }
+            // Streamed residual: this k-tile's requests and the selection fragments for the pieces that are about to
+            // be added go out here, in the lightest load slot of the four (two staging pieces, no fragment reads)
+            f32x4 s0f = {0.f, 0.f, 0.f, 0.f}, s1f = s0f;
+            if constexpr (kIssued > 0) {
+                res_issue(std::integral_constant<int, 0>{});
+                res_issue(std::integral_constant<int, 1>{});
+                res_issue(std::integral_constant<int, 2>{});
+                res_issue(std::integral_constant<int, 3>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (kStream && J >= 1) {
+                const int L16 = fresh_lane() * 16;
+                s0f = *reinterpret_cast<const f32x4 *>(ident_slot + L16);
+                s1f = *reinterpret_cast<const f32x4 *>(ident_slot + 1024 + L16);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (more) {
                 if (!(kQuarters && after)) stage_half(cur + SLOT_B1, p.W, b1_src, koff2);
                 if (++c2_k == p.nk) { c2_k = 0; if (++c2_tile < my_count) { advance(c2m, c2n, c2i); set_c2(); } }
+                // (kIssued: this k-tile's residual plane pieces, younger than its A1 as well)
                 if (after && prev_full) {
-                    if constexpr (kTileStores == 32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+                    if constexpr (kTileStores == 32) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(38 + kIssued) : "memory");
                     else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
                 } else {
-                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + kIssued) : "memory");
                 }
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1567,13 +1748,84 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             TC_PH(10);                             // DMA issue + vmcnt wait
             TC_XBAR();
             TC_PH(11);
-            math(1, 0);                            // ends with the hand-over barrier
+            if constexpr (kStream && J >= 1) {
+                // The plane pieces requested one k-tile ago have landed (the counted wait above).  Lane exchange into
+                // the operand order first (lane frow + 16 fgrp takes what lane 4 frow + fgrp loaded), its latency
+                // under this turn's sixteen MFMAs; then the adds, before the hand-over barrier.
+                constexpr int JP = J - 1;
+                const int Lx = fresh_lane();
+                const int pull = (((Lx & 15) << 2) | (Lx >> 4)) << 2;
+                auto res_xchg = [&](auto uc) __attribute__((always_inline)) {
+                    constexpr int u = decltype(uc)::value, q = JP * STREAM + u;
+                    if constexpr (kXchg && u < STREAM && q < 32) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            rq[JP & 1][u][e] = (unsigned)__builtin_amdgcn_ds_bpermute(pull, (int)rq[JP & 1][u][e]);
+                    }
+                };
+                res_xchg(std::integral_constant<int, 0>{}); res_xchg(std::integral_constant<int, 1>{});
+                res_xchg(std::integral_constant<int, 2>{}); res_xchg(std::integral_constant<int, 3>{});
+                __builtin_amdgcn_sched_barrier(0);
+                math(1, 0, false);
+                __builtin_amdgcn_sched_barrier(0);
+                // in place, by name: D = C is not a constraint of the builtin, and the allocator otherwise moves
+                // the accumulators through spare registers here.  hi planes first, then lo planes: the two adds
+                // into one accumulator are not neighbours in the matrix pipe.
+                auto res_add = [&](auto uc, auto plane_c) __attribute__((always_inline)) {
+                    constexpr int u = decltype(uc)::value, q = JP * STREAM + u;
+                    if constexpr (u < STREAM && q < 32 && (q & 1) == decltype(plane_c)::value) {
+                        constexpr int nq = q >> 4, mi = (q >> 1) & 7;
+#ifndef TC_ABL_NORESMFMA
+                        tc_mfma_bf16_slot<(JP & 1) * 4 + u>(acc[nq * 2][mi], s0f, rq[JP & 1][u]);
+                        tc_mfma_bf16_slot<(JP & 1) * 4 + u>(acc[nq * 2 + 1][mi], s1f, rq[JP & 1][u]);
+#endif
+                    }
+                };
+                res_add(std::integral_constant<int, 0>{}, I0{}); res_add(std::integral_constant<int, 1>{}, I0{});
+                res_add(std::integral_constant<int, 2>{}, I0{}); res_add(std::integral_constant<int, 3>{}, I0{});
+                res_add(std::integral_constant<int, 0>{}, I1{}); res_add(std::integral_constant<int, 1>{}, I1{});
+                res_add(std::integral_constant<int, 2>{}, I1{}); res_add(std::integral_constant<int, 3>{}, I1{});
+                __builtin_amdgcn_sched_barrier(0);
+                TC_XBAR();
+            } else {
+                math(1, 0);                        // ends with the hand-over barrier
+            }
             TC_PH(12);
 #ifdef TC_GEMM_STAMPS
             TC_STAMP(s1);
 #pragma unroll
             for (int i = 0; i < 24; ++i) if (i == (kt < 23 ? kt : 23)) c_kt[i] += s1 - s0;
 #endif
+            ++g;
+        };
+        using Plain = std::integral_constant<int, -1>;
+        if constexpr (kStream) {
+            // kU requesting instances and one more that only adds: the host guarantees nk > res_stream_tiles(STREAM)
+            constexpr int kU = res_stream_tiles(STREAM);
+            ktile(0, std::integral_constant<int, 0>{});
+            ktile(1, std::integral_constant<int, 1>{});
+            ktile(2, std::integral_constant<int, 2>{});
+            ktile(3, std::integral_constant<int, 3>{});
+            ktile(4, std::integral_constant<int, 4>{});
+            ktile(5, std::integral_constant<int, 5>{});
+            ktile(6, std::integral_constant<int, 6>{});
+            ktile(7, std::integral_constant<int, 7>{});
+            ktile(8, std::integral_constant<int, 8>{});
+            if constexpr (kU > 8) {
+                ktile(9, std::integral_constant<int, 9>{});
+                ktile(10, std::integral_constant<int, 10>{});
+                ktile(11, std::integral_constant<int, 11>{});
+            }
+            if constexpr (kU > 11) {
+                ktile(12, std::integral_constant<int, 12>{});
+                ktile(13, std::integral_constant<int, 13>{});
+                ktile(14, std::integral_constant<int, 14>{});
+                ktile(15, std::integral_constant<int, 15>{});
+                ktile(16, std::integral_constant<int, 16>{});
+            }
+            for (int kt = kU + 1; kt < p.nk; ++kt) ktile(kt, Plain{});
+        } else {
+            for (int kt = 0; kt < p.nk; ++kt) ktile(kt, Plain{});
         }
         if constexpr (!kPiece) {
             if (wr == 0) TC_XBAR();               // row group 1's last phase
@@ -1616,12 +1868,12 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
 #endif
     }
 #endif
-    if constexpr (kPiece) finish_tile(ptm, ptn);
+    if constexpr (kPiece) finish_tile(ptm, ptn, (my_count - 1) & 1);
     if constexpr (EPI == TC_EPI_BIAS_RESIDUAL) {
         if (p.row_acc) {                          // the last tile's row sums
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();
-            flush_row_sums(p, smem + BIAS_OFF + ((my_count - 1) & 1) * 8192, ptm);
+            flush_row_sums(p, smem + (kStream ? ROPE_OFF : BIAS_OFF) + ((my_count - 1) & 1) * 8192, ptm);
         }
     }
 }
@@ -1662,9 +1914,11 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
         p.tiles_n = p.N / k256::BN;
         const int ntiles = p.tiles_m * p.tiles_n;
         int grid = ntiles < g_num_cus ? ntiles : g_num_cus;
-#ifdef TC_GEMM_STAMPS
-        { const char *e = getenv("TC_GEMM_GRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
-#endif
+        {
+            static int cap = -1;
+            if (cap < 0) { const char *e = getenv("TC_GEMM_GRID"); cap = e ? atoi(e) : 0; }
+            if (cap > 0 && cap < grid) grid = cap;
+        }
         {
             static int gm = 0;
             if (gm == 0) { const char *e = getenv("TC_GEMM_GM"); gm = e ? atoi(e) : 1; if (gm < 1) gm = 1; }
@@ -1727,7 +1981,38 @@ int launch(const GemmParams &p0, bool big, hipStream_t stream) {
                     }
                     attr_set_f = true;
                 }
-                TC_LAUNCH((gemm256x_kernel<T, EPI, true>), dim3(grid), dim3(512), k256x::LDS_BYTES, stream, p);
+                // the residual planes streamed in under the k-loop: eight k-tiles or more to carry the sixteen pieces of
+                // a tile, plane offsets in 32 bits; TC_RES_STREAM=0 keeps the form that preloads the accumulators
+                bool streamed = false;
+                if constexpr (EPI == TC_EPI_BIAS_RESIDUAL) {
+                    static int want = -1;
+                    if (want < 0) { const char *e = getenv("TC_RES_STREAM"); want = e ? atoi(e) : TC_RES_STREAM_DEFAULT; }
+                    // plane pieces per k-tile: as few as the k-tile count allows (want > 1 forces a count)
+                    int per = p.nk > 16 ? 2 : 3;
+                    if (want >= 2 && want <= 3 && p.nk > res_stream_tiles(want)) per = want;
+                    streamed = want != 0 && p.nk > res_stream_tiles(per) && (long)p.M * p.ldo * 2 < (1L << 32);
+                    if (streamed) {
+                        auto go = [&](auto kern, bool &attr_set) -> int {
+                            if (!attr_set) {
+                                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, k256x::LDS_BYTES);
+                                if (e != hipSuccess) {
+                                    tc_set_error("tc_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                                    return TC_ELAUNCH;
+                                }
+                                attr_set = true;
+                            }
+                            TC_LAUNCH(kern, dim3(grid), dim3(512), k256x::LDS_BYTES, stream, p);
+                            return TC_OK;
+                        };
+                        static bool set2 = false, set3 = false;
+                        int rc = TC_OK;
+                        if (per == 2) rc = go(gemm256x_kernel<T, EPI, true, false, 2>, set2);
+                        else rc = go(gemm256x_kernel<T, EPI, true, false, 3>, set3);
+                        if (rc != TC_OK) return rc;
+                    }
+                }
+                if (!streamed) TC_LAUNCH((gemm256x_kernel<T, EPI, true>), dim3(grid), dim3(512), k256x::LDS_BYTES, stream, p);
             }
         } else if (use_alt) {
             static bool attr_set_x = false;
