@@ -13,4 +13,5 @@ if [ "$1" = "base" ]; then
     cp libtranscodon_hip.so ../../tools/ab/libtc_base.so
 fi
 /opt/rocm/bin/hipcc $FLAGS -DTC_GEMM_STAMPS "$@" -c gemm.hip -o /tmp/gemm_stamps.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libtc_stamps.so $OTHERS /tmp/gemm_stamps.o
+/opt/rocm/bin/hipcc ${FLAGS/-mllvm -amdgpu-mfma-vgpr-form/} -DTC_GEMM_STAMPS "$@" -c gemm_w.hip -o /tmp/gemm_w_stamps.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libtc_stamps.so $OTHERS /tmp/gemm_stamps.o /tmp/gemm_w_stamps.o

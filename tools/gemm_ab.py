@@ -62,6 +62,9 @@ def main():
               "out": (x, E, E, E, _lib.EPI_BIAS_RESIDUAL, E, True),
               "fc1": (x, E, F, E, _lib.EPI_BIAS_GELU, F + 64, False),
               "fc1_bias": (x, E, F, E, _lib.EPI_BIAS, F + 64, False),
+              "out_bias": (x, E, E, E, _lib.EPI_BIAS, E, False),
+              "fc2_bias": (mid, F + 64, E, F, _lib.EPI_BIAS, E, False),
+              "sq_bias": (mid, F + 64, F, F, _lib.EPI_BIAS, F + 64, False),
               "fc2": (mid, F + 64, E, F, _lib.EPI_BIAS_RESIDUAL, E, True),
               # the new build also writes the bf16 copy and the row sums of a folded LayerNorm
               "out_ln": (x, E, E, E, _lib.EPI_BIAS_RESIDUAL, E, True),

@@ -15,7 +15,7 @@ from collections import defaultdict
 
 def short(name):
     """Kernel family of a (possibly mangled) kernel name; None for kernels that are not ours."""
-    m = re.search(r"(gemm128_kernel|gemm256x_kernel|gemm256_kernel|gemm_tn256x_kernel|gemm_tn256_kernel|gemm_tn_kernel|mlm_mask_kernel|attn_bwd_dq_bf16_kernel|attn_bwd_dkv_bf16_kernel|"
+    m = re.search(r"(gemm128_kernel|gemm256w_kernel|gemm256x_kernel|gemm256_kernel|gemm_tn256x_kernel|gemm_tn256_kernel|gemm_tn_kernel|mlm_mask_kernel|attn_bwd_dq_bf16_kernel|attn_bwd_dkv_bf16_kernel|"
                   r"attn_bf16_kernel|attn_f32_kernel|layernorm_bwd_kernel|layernorm_kernel|head_bwd_kernel|"
                   r"head_rows_kernel|head_kernel|ln_rows_finalize_kernel|embed_bwd_kernel|embed_kernel|decode_kernel|key_mask_kernel|colsum_kernel|"
                   r"reduce_slabs_kernel|rope_bwd_kernel|adamw_kernel|delta_kernel|transpose_kernel)", name)
@@ -23,18 +23,25 @@ def short(name):
         return None
     base = m.group(1)
     if base.startswith("gemm1") or base.startswith("gemm2"):
-        e = re.search(r"Li(\d)E", name) or re.search(r",\s*(\d)\s*>", name)
+        # the epilogue is the second template argument
+        e = re.search(r"Li(\d)E", name) or re.search(r"<[^,<>]+,\s*(\d)\s*[,>]", name)
         # the profiler's demangler garbles the <__bf16, 1> instantiation into "<bool _Accum, int, E>"
         # the profiler's demangler also garbles the three-argument forms: "<bool _Accum, int, ELb, E>" is
         # <__bf16, 3, true>, "<bool _Accum, int, E, true>" is <__bf16, 1, true>, "<bool _Accum, int, EL, bool, E>"
         # is <__bf16, 2, true>
+        # (five template arguments since the streamed residual: <T, EPI, FOLD, PANELS, STREAM>)
         if "_Accum" in name and "EL, bool, E" in name:
-            base += "<epi=2>+split"         # <__bf16, 2, true>: residual product on the bf16 hi/lo planes
+            base += "<epi=2>+split"         # <__bf16, 2, true, ...>: residual product on the bf16 hi/lo planes
+            m2 = re.search(r"EL, bool, E, (?:false|true), (\d)", name)
+            if m2 and m2.group(1) != "0":
+                base += "+stream%s" % m2.group(1)
         elif "_Accum" in name and "ELb, E" in name:
             base += "<epi=3>+ln"
+            if re.search(r"ELb, E, true", name):
+                base += "+panels"
         else:
             base += "<epi=%s>" % (e.group(1) if e else ("1" if "_Accum" in name else "?"))
-            if "ELb1E" in name or ", true>" in name:
+            if "ELb1E" in name or ", true>" in name or re.search(r"_Accum, int, E, true", name):
                 base += "+ln"          # the variant with a LayerNorm folded in
         if "IfLi" in name or "<float" in name:
             base += "f32"
