@@ -47,7 +47,7 @@ for name in names:
     ldo = N + 64 if N == F else N      # rows of 6144 bytes store slowly: pad them
     out = torch.empty(M, ldo, device=dev, dtype=torch.float32 if epi in (2, 4, 5) else torch.bfloat16)
     s = torch.cuda.current_stream().cuda_stream
-    for it in range(3):
+    for it in range(int(os.environ.get("TC_STAMP_REPS", "3"))):
         stamps.zero_()
         if epi == 5:
             rc = lib.tc_gemm_residual_split(1, a.data_ptr(), a.shape[1], w.data_ptr(), b.data_ptr(), plane_hi.data_ptr(), plane_lo.data_ptr(),
@@ -65,7 +65,8 @@ for name in names:
         m = st[:, grp].mean(0)
         tiles = float(m[26])
         per = [round(float(v) / tiles) for v in m[:24] if v > 0]
-        print(f"{name} group {grp}: tiles/WG {tiles:.1f} total {m[25]:.0f} per tile {m[25] / tiles:.0f}  epilogue/tile {m[24] / tiles:.0f}  "
+        ghz = float(m[25]) / max(float(m[27]), 1.0) * 0.1      # shader clocks per 100 MHz tick
+        print(f"{name} group {grp}: in-kernel clock {ghz:.2f} GHz  tiles/WG {tiles:.1f} total {m[25]:.0f} per tile {m[25] / tiles:.0f}  epilogue/tile {m[24] / tiles:.0f}  "
               f"k-tile by position {per}", flush=True)
         if float(ph.sum()) > 0:          # library built with -DTC_GEMM_PHASES: a tile's first and last k-tile
             for c, cname in enumerate(("first", "last")):

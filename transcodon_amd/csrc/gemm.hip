@@ -453,6 +453,19 @@ __device__ __forceinline__ void put_row_sums(char *planes, int wm, int wn, int b
     if (fgrp == 0) *reinterpret_cast<f32x2 *>(planes + (wn * 256 + wm * 64 + block_off + frow) * 8) = f32x2{s1, s2};
 }
 
+// Stores of the large-tile epilogues go through BOUNDED buffer descriptors (num_records = the bytes of the M valid
+// rows): a row past M is dropped by the hardware, so no store sits behind a branch, every store instruction of a tile
+// is always issued (the counted vmcnt waits rely on that) and the compiler is free to keep the lane exchanges of
+// several row blocks in flight instead of waiting for each one before its store.  Offsets are 32-bit: the host
+// keeps (M + 256) * ldo * element size below 4 GiB for these kernels.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tc_out_rsrc(const void *base, int rows, int ld, int esz) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)((unsigned)rows * (unsigned)ld * (unsigned)esz),
+                                             0x00020000);
+}
+__device__ __forceinline__ void tc_bstore16(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, unsigned byte_off) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, 0, 0);
+}
+
 // Epilogue of one wave tile.  Phase 1: arithmetic in place (its table loads are not queued
 // behind any store); phase 2: all stores.
 template <typename T, int EPI, int LAY = 0, int MI0 = 0, int MI1 = 8, int NI0 = 0, int NI1 = 4, bool LDSX = false,
@@ -502,10 +515,11 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
         asm volatile("" : "+v"(L));                         // keeps the address arithmetic below out of the k-loop                  // lane exchange as for the final stores
             const int pull = (((L & 3) << 4) | (L >> 2)) << 2;
             const int mbase = tm * BM + wm * 64 + (L >> 2), nbase = tn * BN + wn * 32 + (L & 3) * 8;
+            const __amdgpu_buffer_rsrc_t rs2 = tc_out_rsrc(p.out2, p.M, p.ldo, 2);
 #pragma unroll
             for (int mi = MI0; mi < MI1; ++mi) {
                 const int m = mbase + mi_off<LAY>(mi);
-                const long orow = (long)m * p.ldo + nbase;
+                const unsigned orow = (unsigned)m * (unsigned)p.ldo + (unsigned)nbase;
 #pragma unroll
                 for (int ni = NI0; ni < NI1; ni += 2) {
                     const f32x4 v = acc[ni][mi], v2 = acc[ni + 1][mi];
@@ -516,7 +530,7 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
                     w[3] = tc_pack_bf16(v2[2], v2[3]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) w[e] = (unsigned)__builtin_amdgcn_ds_bpermute(pull, (int)w[e]);
-                    if (m < p.M) *reinterpret_cast<u32x4 *>(p.out2 + (orow + ni_off<LAY>(ni)) * 2) = w;
+                    tc_bstore16(rs2, w, (orow + ni_off<LAY>(ni)) * 2u);
                 }
             }
         } else {
@@ -737,10 +751,14 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
                 }
             }
         }
+        // bounded descriptors: rows past p.M are dropped by the hardware (see tc_out_rsrc)
+        const __amdgpu_buffer_rsrc_t rs_out = tc_out_rsrc(p.out, p.M, p.ldo, kF32Out && !SPLIT ? 4 : 2);
+        const __amdgpu_buffer_rsrc_t rs_out2 = tc_out_rsrc(p.out2, p.out2 ? p.M : 0, p.ldo, 2);
+        const __amdgpu_buffer_rsrc_t rs_lo = tc_out_rsrc(p.out_lo, SPLIT ? p.M : 0, p.ldo, 2);
 #pragma unroll
         for (int mi = MI0; mi < MI1; ++mi) {
             const int m = mbase + mi_off<LAY>(mi) + trow;
-            const long orow = (long)m * p.ldo + nbase;
+            const unsigned orow = (unsigned)m * (unsigned)p.ldo + (unsigned)nbase;
             if constexpr (LAY == 2 && !kF32Out) {
 #pragma unroll
                 for (int ni = NI0; ni < NI1; ni += 2) {
@@ -751,7 +769,7 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
                     w[2] = tc_pack_bf16(v2[0], v2[1]);
                     w[3] = tc_pack_bf16(v2[2], v2[3]);
                     w = exchange(w);
-                    if (m < p.M) *reinterpret_cast<u32x4 *>(p.out + (orow + ni_off<LAY>(ni)) * 2) = w;
+                    tc_bstore16(rs_out, w, (orow + ni_off<LAY>(ni)) * 2u);
                 }
             } else if constexpr (SPLIT) {
                 // result as two bf16 planes, hi = bf16(v), lo = bf16(v - hi): one 16-byte store each
@@ -773,10 +791,8 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
                     l[3] = tc_pack_bf16(v2[2] - tc_bf16_lo(h[3]), v2[3] - tc_bf16_hi(h[3]));
                     h = exchange(h);
                     l = exchange(l);
-                    if (m < p.M) {
-                        *reinterpret_cast<u32x4 *>(p.out2 + (orow + ni_off<LAY>(ni)) * 2) = h;
-                        *reinterpret_cast<u32x4 *>(p.out_lo + (orow + ni_off<LAY>(ni)) * 2) = l;
-                    }
+                    tc_bstore16(rs_out2, h, (orow + ni_off<LAY>(ni)) * 2u);
+                    tc_bstore16(rs_lo, l, (orow + ni_off<LAY>(ni)) * 2u);
                 }
                 if (stat_lds) put_row_sums(stat_lds, wm, wn, mi_off<LAY>(mi), frow, fgrp, s1, s2);
             } else {
@@ -784,20 +800,20 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
 #pragma unroll
                 for (int ni = NI0; ni < NI1; ni += (LAY == 2 ? 2 : 1)) {
                     const u32x4 w = exchange(__builtin_bit_cast(u32x4, acc[ni][mi]));
-                    if (m < p.M) *reinterpret_cast<u32x4 *>(p.out + (orow + ni_off<LAY>(ni)) * 4) = w;
+                    tc_bstore16(rs_out, w, (orow + ni_off<LAY>(ni)) * 4u);
                     if constexpr (LAY == 2) {
                         // interleaved column order: the pair's second tile is the lane's next 4 columns
                         const u32x4 w2 = exchange(__builtin_bit_cast(u32x4, acc[ni + 1][mi]));
-                        if (m < p.M) *reinterpret_cast<u32x4 *>(p.out + (orow + ni_off<LAY>(ni + 1)) * 4) = w2;
+                        tc_bstore16(rs_out, w2, (orow + ni_off<LAY>(ni + 1)) * 4u);
                         if constexpr (EPI == TC_EPI_BIAS_RESIDUAL) {
-                            if (p.out2 && m < p.M) {              // bf16 copy for the folded LayerNorm's product
+                            if (p.out2) {                         // bf16 copy for the folded LayerNorm's product
                                 const f32x4 f = __builtin_bit_cast(f32x4, w), f2 = __builtin_bit_cast(f32x4, w2);
                                 u32x4 h;
                                 h[0] = tc_pack_bf16(f[0], f[1]);
                                 h[1] = tc_pack_bf16(f[2], f[3]);
                                 h[2] = tc_pack_bf16(f2[0], f2[1]);
                                 h[3] = tc_pack_bf16(f2[2], f2[3]);
-                                *reinterpret_cast<u32x4 *>(p.out2 + (orow + ni_off<LAY>(ni)) * 2) = h;
+                                tc_bstore16(rs_out2, h, (orow + ni_off<LAY>(ni)) * 2u);
                             }
                         }
                     }
@@ -1469,6 +1485,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
 #ifdef TC_GEMM_STAMPS
     unsigned long long c_kt[24] = {}, c_epi = 0;
     TC_STAMP(k_begin);
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();   // 100 MHz: gives the clock the kernel ran at
 #endif
 #ifdef TC_GEMM_PHASES
     // Hand-over profile: only a tile's first and last k-tile carry stamps (13 points each); slots
@@ -1497,8 +1514,9 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             init_acc256<T, EPI, kLay, 0, 8, 0, 4, kSplit>(p, acc, mrow0, ncol0);
             if (wr == 1) TC_XBAR();
         }
-        bool prev_full = kPiece && t > 0 && ptm * BM + BM <= p.M;
-        if constexpr (PANELS) prev_full = t > 0 && p.panels[4 * ptm + 1] - p.panels[4 * ptm] == BM;
+        // every store instruction of the previous tile's epilogue was issued, row tail or not (bounded descriptors
+        // drop the rows past the end), so the counted waits below always hold
+        const bool prev_full = kPiece && t > 0;
 
         // The unrolled k-tiles of the streamed form name the accumulators in fixed registers at every k-tile
         // boundary: without that the register allocator renames them from copy to copy of the body and pays
@@ -1815,6 +1833,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         unsigned long long *o = p.stamps + (blockIdx.x * 2 + (threadIdx.x >> 8)) * 32;
         for (int i = 0; i < 24; ++i) o[i] = c_kt[i];
         o[24] = c_epi; o[25] = k_end - k_begin; o[26] = my_count;
+        o[27] = __builtin_amdgcn_s_memrealtime() - rt_begin;
 #ifdef TC_GEMM_PHASES
         unsigned long long *o2 = p.stamps + 256 * 2 * 32 + (blockIdx.x * 2 + (threadIdx.x >> 8)) * 26;
         for (int c = 0; c < 2; ++c)
@@ -2093,8 +2112,11 @@ static int gemm_impl(int dtype, int epilogue, const void *A, int lda, const void
     }
     // the large tile needs N % 256 == 0 (and, for the fused q/k/v epilogue, E % 256 == 0 so that
     // a tile never straddles two sections) and enough tiles to occupy every CU
+    // (32-bit byte offsets: operands, and the result rows up to the end of the last tile)
+    const int out_esz = (epilogue == TC_EPI_BIAS_RESIDUAL && !split_lo) || epilogue == TC_EPI_PLAIN_F32 ? 4 : esz;
     bool big = N % 256 == 0 && (long)(panels ? n_panels : (M + 255) / 256) * (N / 256) >= g_num_cus &&
-               (long)M * lda * esz < (1L << 32) && (long)N * K * esz < (1L << 32);
+               (long)M * lda * esz < (1L << 32) && (long)N * K * esz < (1L << 32) &&
+               ((long)M + 256) * ldo * out_esz < (1L << 32);
     if (epilogue == TC_EPI_QKV_ROPE && (N / 3) % 256 != 0) big = false;
     if (dtype != TC_BF16) big = false;   // the f32 path is MFMA-rate bound (1/16 of bf16): small tile is enough
     if (splits > 1) big = false;
