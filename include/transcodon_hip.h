@@ -366,7 +366,13 @@ int tc_attn_bwd_static(int dtype, const void *qkv, int ldq, const uint64_t *key_
  *                      products move the same bytes as with an f32 stream and the hi plane IS the operand of
  *                      the next product: no copy is written.
  * tc_gemm_residual_split  x += A W^T + b on the plane pair in place, plus the row sums of the new hi plane
- *                      (row_acc as for tc_gemm_residual_ln).
+ *                      (row_acc as for tc_gemm_residual_ln).  From K = 768 on (twelve 64-deep k-tiles or more) the
+ *                      planes are not loaded ahead of the k-loop but streamed in under it and added to the
+ *                      accumulators by the matrix unit (1.0 x bf16 products, exact), the bias last: the f32 sum is
+ *                      then rounded in another order than tc_gemm(TC_EPI_BIAS_RESIDUAL) rounds it (the pair agrees
+ *                      with that product to 2^-15 of the value plus 2^-16 absolute, the hi plane differs from its
+ *                      bf16 rounding in fewer than 2 elements in 1000, by one bf16 step).  Environment
+ *                      TC_RES_STREAM=0 keeps the load-ahead form for every K.  M * ldo * 2 must stay below 4 GiB.
  * tc_layernorm_fwd_split  tc_layernorm_fwd reading the plane pair;  tc_split_to_f32: out[i] = hi[i] + lo[i].
  * tc_gemm_residual_ln  tc_gemm(TC_EPI_BIAS_RESIDUAL) that also writes out_bf16 [M,ldo] = bf16(out) and
  *                      adds, per row, the sum and the sum of squares of the bf16-rounded results to
