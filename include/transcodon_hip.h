@@ -32,7 +32,7 @@ extern "C" {
 /* Changes whenever a struct layout or a signature of this header changes; a caller built against another
  * value must not call into the library.  tc_struct_bytes lets a binding that restates the structs (ctypes)
  * verify its own layout: which = 0 tc_layer_weights, 1 tc_encoder_desc, 2 tc_layer_grads, 3 tc_encoder_grads. */
-#define TC_VERSION 120
+#define TC_VERSION 130
 
 /* status codes */
 #define TC_OK 0
@@ -460,6 +460,12 @@ typedef struct tc_encoder_desc {
     const float *st_ln_g, *st_ln_b;      /* structure_linear.layer_norm                 */
     const float *st_w;                   /* structure_linear.out_proj.weight [n_struct,E] */
     const float *st_bias;                /* out_proj.bias + structure_linear.bias        */
+    /* Optional (all three or none, bf16 only): emb_layer_norm_after folded into the two head dense layers, as
+     * tc_ln_fold_weights makes them from (w_heads in f32, lnf_g, lnf_b, b_heads).  Used by a folded forward
+     * (see tc_layer_weights) that is not asked for rep_last: the last fc2's row sums then serve the head product
+     * and no LayerNorm kernel runs at all (model.py:232-240 become part of the [2E,E] product). */
+    const void *w_heads_ln;              /* [2E,E] bf16(gamma o W)                       */
+    const float *c_heads_ln, *s_heads_ln; /* [2E]                                        */
 } tc_encoder_desc;
 
 /* Bytes of device workspace tc_encoder_forward needs for B sequences of T tokens. */

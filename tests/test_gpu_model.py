@@ -317,6 +317,48 @@ def test_folded_layernorm_forward_against_separate_kernels_and_oracle(full_sd, f
             assert float(d.max()) < 0.15, (fold, layer, float(d.max()))
 
 
+def test_final_layernorm_folded_into_the_head_products(full_sd, full_bf16):
+    """A folded forward that is not asked for representations[12] (what the batched codon driver calls) applies
+    emb_layer_norm_after inside the two head dense layers (model.py:232-240): no LayerNorm kernel at all, 24
+    row-statistics launches, logits and structure logits within the bf16 tolerance of the oracle and as close to it
+    as the forward that runs the final LayerNorm as a kernel."""
+    from transcodon_amd import _lib
+    rng = np.random.default_rng(101)
+    B, T = 64, 512
+    tok = rng.integers(5, 10, (B, T))
+    tok[:, 0] = O.CLS
+    tok[:, -1] = O.EOS
+    tok[7, 300:] = 1
+    tok[7, 299] = O.EOS
+    sp = rng.integers(0, 1438, B)
+    t_d, s_d = torch.from_numpy(tok).to(DEV), torch.from_numpy(sp).to(DEV)
+    lib = _lib.load()
+    runs = {}
+    for reps in ((), (12,)):
+        lib.tc_prof_reset()
+        lib.tc_prof_enable(1)
+        with torch.no_grad():
+            out = full_bf16(t_d, s_d, repr_layers=list(reps))
+        torch.cuda.synchronize()
+        lib.tc_prof_enable(0)
+        runs[reps] = (out["logits"].float().cpu().numpy(), out["struct_label_output"].float().cpu().numpy(),
+                      _lib.prof_collect(_lib.PROF_LN_ROWS)[0], _lib.prof_collect(_lib.PROF_LAYERNORM)[0])
+    assert runs[()][2] == 24 and runs[()][3] == 0
+    assert runs[(12,)][2] == 23 and runs[(12,)][3] == 1
+    rows = [0, 7, 33]
+    ref = O.forward(full_sd, O.FULL, torch.from_numpy(tok[rows]), torch.from_numpy(sp[rows]))
+    keep = tok[rows] != 1
+    err = {}
+    for reps in ((), (12,)):
+        got = runs[reps][0][rows]
+        _check(got, ref["logits"].numpy(), keep, torch.bfloat16)
+        err[reps] = float(np.sqrt(np.mean((got - ref["logits"].numpy())[keep] ** 2)))
+    print(f"\nrms logit error against the oracle: final LayerNorm folded {err[()]:.4e}, as a kernel {err[(12,)]:.4e}")
+    assert err[()] <= 1.25 * err[(12,)] + 1e-4
+    ds = np.abs(runs[()][1][rows] - ref["struct_label_output"].numpy())[keep]
+    assert float(ds.max()) <= BF16_ATOL, float(ds.max())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_multihead_attention_module_against_oracle(dtype):
     """MultiheadAttention.forward on its own (the sub-module API of multihead_attention.py:162-408):

@@ -147,6 +147,8 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
         const tc_layer_weights &lw = d->layers[l];
         fold = lw.w_qkv_ln && lw.c_qkv_ln && lw.s_qkv_ln && lw.w_fc1_ln && lw.c_fc1_ln && lw.s_fc1_ln;
     }
+    // emb_layer_norm_after folded into the head dense layers as well: nobody asked for its output
+    const bool fold_heads = fold && !rep_last && d->w_heads_ln && d->c_heads_ln && d->s_heads_ln;
     if (fold) {
         // (a kernel: a memset node of a captured graph is not ordered against the graph's previous launch)
         TC_TRY(tc_ln_rows_clear(w.row_acc, (int)w.rows_pad, stream));
@@ -177,10 +179,9 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
                               w.ld_mid, M, F, E, 0.f, nullptr, nullptr, 0, 0, stream));
             TC_TRY(tc_gemm_residual_split(dt, w.mid, w.ld_mid, lw.w_fc2, lw.b_fc2, w.xb, x_lo, w.row_acc, E, M, E, F,
                                           stream));
-            if (!last) {
-                TC_TRY(tc_ln_rows_finalize(w.row_acc, w.ln_rows, M, E, d->ln_eps, stream));
-                TC_TRY(save_rep(l + 1));
-            }
+            // (after the last layer the row sums serve the head product when the final LayerNorm is folded into it)
+            if (!last || fold_heads) TC_TRY(tc_ln_rows_finalize(w.row_acc, w.ln_rows, M, E, d->ln_eps, stream));
+            if (!last) TC_TRY(save_rep(l + 1));
             continue;
         }
         TC_TRY(ln(lw.ln1_g, lw.ln1_b, nullptr));
@@ -196,7 +197,11 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
     }
 
     // final LayerNorm; the f32 copy doubles as representations[num_layers]
-    if (fold) {
+    const int nheads = struct_logits ? 2 : 1;
+    if (fold_heads) {
+        TC_TRY(tc_gemm_ln(dt, TC_EPI_BIAS_GELU, w.xb, E, d->w_heads_ln, d->c_heads_ln, d->s_heads_ln, w.ln_rows, w.mid,
+                          w.ld_mid, M, nheads * E, E, 0.f, nullptr, nullptr, 0, 0, stream));
+    } else if (fold) {
         TC_TRY(tc_layernorm_fwd_split(w.xb, x_lo, d->lnf_g, d->lnf_b, rep_last, w.h, M, E, d->ln_eps, stream));
     } else if (bf) {
         TC_TRY(tc_layernorm_fwd(w.x, d->lnf_g, d->lnf_b, rep_last, w.h, M, E, d->ln_eps, stream));
@@ -206,9 +211,9 @@ extern "C" int tc_encoder_forward(const tc_encoder_desc *d, const int32_t *token
             TC_TRY(tc_copy_f32(rep_last, static_cast<const float *>(w.h), (long)M * E, stream));
         }
     }
-    const int nheads = struct_logits ? 2 : 1;
-    TC_TRY(tc_gemm(dt, TC_EPI_BIAS_GELU, w.h, E, d->w_heads, d->b_heads, nullptr, w.mid, w.ld_mid, M,
-                   nheads * E, E, 0.f, nullptr, nullptr, 0, 0, stream));
+    if (!fold_heads)
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS_GELU, w.h, E, d->w_heads, d->b_heads, nullptr, w.mid, w.ld_mid, M,
+                       nheads * E, E, 0.f, nullptr, nullptr, 0, 0, stream));
     TC_TRY(tc_head_logits_fwd(dt, w.mid, w.ld_mid, 0, d->lm_ln_g, d->lm_ln_b, d->tok_table, d->lm_bias,
                               logits, M, E, d->vocab, d->ln_eps, stream));
     if (struct_logits)

@@ -345,7 +345,9 @@ def _optimize(model, items, dev, max_batch_tokens, packed):
             species = torch.tensor([c[4] for c in chunk], dtype=torch.int32)
             row0 = [r * width + c[2] for r, c in enumerate(chunk)]
             with torch.no_grad():
-                logits = model(tok.to(dev), species.to(dev))["logits"].view(B * width, -1)
+                # (no representation asked for: the decode reads logits only, and a large folded batch then runs
+                # without any LayerNorm kernel)
+                logits = model(tok.to(dev), species.to(dev), repr_layers=[])["logits"].view(B * width, -1)
         bases = ops.codon_decode(
             logits,
             torch.frombuffer(bytearray(aa_all), dtype=torch.uint8).to(dev),

@@ -195,8 +195,30 @@ class ProteinBertModel(nn.Module):
             for name in ("lnf_g", "lnf_b", "w_heads", "b_heads", "lm_ln_g", "lm_ln_b", "lm_bias",
                          "st_ln_g", "st_ln_b", "st_w", "st_bias"):
                 setattr(d, name, keep[name].data_ptr())
+            if dtype == torch.bfloat16 and self.fold_layernorm:
+                # emb_layer_norm_after folded into the two head dense layers (model.py:232-240): used by a
+                # folded forward that is not asked for the last representation
+                w_heads32 = torch.cat([own[4].detach(), own[9].detach()]).float().contiguous()
+                wf, sh, ch = self._fold_weights(w_heads32, keep["lnf_g"], keep["lnf_b"], keep["b_heads"], device)
+                keep["w_heads_ln"], keep["s_heads_ln"], keep["c_heads_ln"] = wf, sh, ch
+                for name in ("w_heads_ln", "s_heads_ln", "c_heads_ln"):
+                    setattr(d, name, keep[name].data_ptr())
         self._pack = {"key": key, "desc": d, "layers": layers, "keep": keep, "per_layer": per_layer}
         return self._pack
+
+    @staticmethod
+    def _fold_weights(W, g, b, bias, device):
+        """tc_ln_fold_weights on one weight matrix: (bf16(gamma o W), its row sums, beta W^T + bias)."""
+        lib = _lib.load()
+        N, K = W.shape
+        wf = torch.empty(N, K, dtype=torch.bfloat16, device=device)
+        s = torch.empty(N, dtype=torch.float32, device=device)
+        c = torch.empty(N, dtype=torch.float32, device=device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        check(lib.tc_ln_fold_weights(W.data_ptr(), g.data_ptr(), b.data_ptr(), bias.data_ptr(), wf.data_ptr(),
+                                     s.data_ptr(), c.data_ptr(), N, K, stream), "tc_ln_fold_weights")
+        torch.cuda.current_stream(device).synchronize()      # W may be freed after this
+        return wf, s, c
 
     @staticmethod
     def _fold_layer(l, pk, device):
