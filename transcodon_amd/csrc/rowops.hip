@@ -3,6 +3,7 @@
 // wave-wide shuffles, no LDS.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -416,6 +417,101 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const T *__restrict__ g,
     }
 }
 
+// The same head on the matrix unit, for bf16 input (the head dense layers' GELU output).  With G = gamma o W,
+//     logit[o] = rstd (sum_k v[k] G[o][k] - mean s[o]) + c[o],   s[o] = sum_k G[o][k],  c[o] = sum_k beta[k] W[o][k] + bias[o],
+// so one pass over a row gives everything: the V products with G, sum v (a row of ones appended to G) and
+// sum v^2 (the diagonal of v v^T: the row fragments serve as BOTH operands of a third MFMA, whose A and B layouts
+// hold the same registers).  G stays f32-accurate as a bf16 pair hi + lo (two MFMAs into one accumulator).  A
+// wave takes 16 rows at a time: lane (row j = lane & 15, k group = lane >> 4) loads 16 bytes per 32-column step,
+// 24 loads in flight, then 72 MFMAs; no per-row chain of wave reductions is left (the register-weights kernel
+// above is bound by those: 350 vector instructions per row), the kernel runs at the speed of its loads.
+template <int V>
+__global__ __launch_bounds__(256) void head_mfma_kernel(const uint16_t *__restrict__ g, int ldg, int col0,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        const float *__restrict__ W, const float *__restrict__ bias,
+                                                        float *__restrict__ out, int M, int E, float eps) {
+    static_assert(V >= 1 && V <= 14, "V products + the row of ones fit one 16-row operand");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int steps = E >> 5;                        // 32 columns per MFMA
+    // LDS: fragment (step, plane) of G at ((step * 2 + plane) * 64 + lane) * 16; then s[16], c[16]
+    float *sc = reinterpret_cast<float *>(smem + steps * 2 * 1024);
+    {
+        const int i = lane & 15, kg = lane >> 4;     // operand row (output) i, k group
+        for (int st = wid; st < steps; st += 4) {
+            const int k0 = st * 32 + kg * 8;
+            u32x4 hi = {0u, 0u, 0u, 0u}, lo = hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = 0.f, b = 0.f;
+                if (i < V) {
+                    a = gamma[k0 + 2 * e] * W[(long)i * E + k0 + 2 * e];
+                    b = gamma[k0 + 2 * e + 1] * W[(long)i * E + k0 + 2 * e + 1];
+                } else if (i == V) {
+                    a = b = 1.0f;
+                }
+                hi[e] = tc_pack_bf16(a, b);
+                lo[e] = tc_pack_bf16(a - tc_bf16_lo(hi[e]), b - tc_bf16_hi(hi[e]));
+            }
+            *reinterpret_cast<u32x4 *>(smem + ((st * 2 + 0) * 64 + lane) * 16) = hi;
+            *reinterpret_cast<u32x4 *>(smem + ((st * 2 + 1) * 64 + lane) * 16) = lo;
+        }
+        // s and c of output o by wave o & 3 (sums of the values the MFMAs multiply: hi + lo)
+        for (int o = wid; o < V; o += 4) {
+            float s1 = 0.f, c1 = 0.f;
+            for (int k = lane; k < E; k += 64) {
+                const float gw = gamma[k] * W[(long)o * E + k];
+                const uint32_t h = tc_pack_bf16(gw, 0.f);
+                const uint32_t l = tc_pack_bf16(gw - tc_bf16_lo(h), 0.f);
+                s1 += tc_bf16_lo(h) + tc_bf16_lo(l);
+                c1 += beta[k] * W[(long)o * E + k];
+            }
+            s1 = tc_wave_sum(s1);
+            c1 = tc_wave_sum(c1);
+            if (lane == 0) { sc[o] = s1; sc[16 + o] = c1 + bias[o]; }
+        }
+    }
+    __syncthreads();
+    const int j = lane & 15, rg = lane >> 4;
+    const float inv_e = 1.0f / (float)E;
+    const int nblk = (M + 15) >> 4;
+    for (int blk = blockIdx.x * 4 + wid; blk < nblk; blk += gridDim.x * 4) {
+        const int row = blk * 16 + j;
+        const uint16_t *src = g + (long)(row < M ? row : M - 1) * ldg + col0 + rg * 8;
+        u32x4 vf[32];                                // E <= 1024
+#pragma unroll
+        for (int st = 0; st < 32; ++st)
+            if (st < steps) vf[st] = *reinterpret_cast<const u32x4 *>(src + st * 32);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, gram = acc;
+#pragma unroll
+        for (int st = 0; st < 32; ++st) {
+            if (st < steps) {
+                const bf16x8 v = __builtin_bit_cast(bf16x8, vf[st]);
+                const bf16x8 gh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(smem + ((st * 2 + 0) * 64 + lane) * 16));
+                const bf16x8 gl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(smem + ((st * 2 + 1) * 64 + lane) * 16));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh, v, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl, v, acc, 0, 0, 0);
+                gram = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v, v, gram, 0, 0, 0);
+            }
+        }
+        // lane (j, rg) holds acc[e] = D[o = 4 rg + e][row j] and gram[e] = (v v^T)[4 rg + e][j]
+        const float own_sum = acc[V & 3];            // meaningful in the lanes with rg == V >> 2
+        const float diag = (j & 3) == 0 ? gram[0] : (j & 3) == 1 ? gram[1] : (j & 3) == 2 ? gram[2] : gram[3];
+        const float sum_v = __shfl(own_sum, j + 16 * (V >> 2), 64);
+        const float sum_v2 = __shfl(diag, j + 16 * (j >> 2), 64);
+        const float mean = sum_v * inv_e;
+        const float var = fmaxf(sum_v2 * inv_e - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + eps);
+        if (row < M) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int o = rg * 4 + e;
+                if (o < V) out[(long)row * V + o] = rstd * (acc[e] - mean * sc[o]) + sc[16 + o];
+            }
+        }
+    }
+}
+
 // ---- greedy synonymous-codon decode ----------------------------------------------------------
 // Amino-acid code = index into "FLIMVPTAY_HQNKDECWRSG"; codons in the table order of the
 // reference; bases coded 0..3 = A,U,C,G (logit columns 5..8).
@@ -818,6 +914,35 @@ extern "C" int tc_head_logits_fwd(int dtype, const void *g, int ldg, int col0, c
     TcProfScope prof(TC_PROF_HEAD, s, (double)M * (E * (double)esz + 4.0 * V));
     const dim3 grid((M + 3) / 4), block(256);
     const int nch = (E + 255) / 256;
+    // bf16 rows of the model's widths: the matrix-unit form (TC_HEAD_MFMA=0 keeps the wave-per-row kernels)
+    {
+        static int mfma = -1;
+        if (mfma < 0) { const char *e = getenv("TC_HEAD_MFMA"); mfma = e ? atoi(e) != 0 : 1; }
+        if (mfma && dtype == TC_BF16 && (V == 10 || V == 3) && E % 32 == 0 && ldg % 8 == 0 && col0 % 8 == 0 && M >= 16) {
+            const int lds = (E / 32) * 2 * 1024 + 128;
+            const int nblk = (M + 15) / 16;
+            const dim3 mgrid((nblk + 3) / 4 < 768 ? (nblk + 3) / 4 : 768);
+            static bool attr10 = false, attr3 = false;
+            bool &attr = V == 10 ? attr10 : attr3;
+            if (!attr) {
+                const void *fn = V == 10 ? reinterpret_cast<const void *>(head_mfma_kernel<10>)
+                                         : reinterpret_cast<const void *>(head_mfma_kernel<3>);
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 128) != hipSuccess) {
+                    tc_set_error("tc_head_logits_fwd: hipFuncSetAttribute failed");
+                    return TC_ELAUNCH;
+                }
+                attr = true;
+            }
+            if (V == 10)
+                TC_LAUNCH((head_mfma_kernel<10>), mgrid, block, lds, s, static_cast<const uint16_t *>(g), ldg, col0, gamma, beta, W,
+                          bias, out, M, E, eps);
+            else
+                TC_LAUNCH((head_mfma_kernel<3>), mgrid, block, lds, s, static_cast<const uint16_t *>(g), ldg, col0, gamma, beta, W,
+                          bias, out, M, E, eps);
+            TC_CHECK_LAUNCH("tc_head_logits_fwd");
+            return TC_OK;
+        }
+    }
     if (nch == 3 && (V == 10 || V == 3)) {
         // the model's own heads: weights in registers, rows by grid stride (1024 workgroups: 4 per CU)
         const dim3 rgrid((M + 3) / 4 < 1024 ? (M + 3) / 4 : 1024);
