@@ -93,7 +93,7 @@ def test_residual_product_writes_copy_and_row_sums():
     np.testing.assert_allclose(rows[:, 1].cpu().numpy(), (-rstd * mean).cpu().numpy(), rtol=2e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("Mr,K", [(M, 768), (M, 3072), (M, 256), (30 * 1024 + 700, 768)])
+@pytest.mark.parametrize("Mr,K", [(M, 768), (M, 3072), (M, 256), (30 * 1024 + 700, 768), (M, 1024), (M, 1088), (M, 704)])
 def test_residual_product_on_split_planes(Mr, K):
     """x = hi + lo (two bf16 planes) updated in place by tc_gemm_residual_split: the new pair represents
     the f32 result of the plain residual product on the same x to 16 bits of mantissa, hi is its bf16
@@ -116,6 +116,11 @@ def test_residual_product_on_split_planes(Mr, K):
     acc = torch.zeros(Mr, 2, dtype=torch.int64, device=DEV)
     _lib.check(lib.tc_gemm_residual_split(_lib.TC_BF16, a.data_ptr(), K, w.data_ptr(), bias.data_ptr(), hi.data_ptr(),
                                           lo.data_ptr(), acc.data_ptr(), E, Mr, E, K, _stream()), "tc_gemm_residual_split")
+    # without row accumulators (NULL is allowed) the planes come out the same
+    hi2, lo2 = x.to(torch.bfloat16), (x - x.to(torch.bfloat16).float()).to(torch.bfloat16)
+    _lib.check(lib.tc_gemm_residual_split(_lib.TC_BF16, a.data_ptr(), K, w.data_ptr(), bias.data_ptr(), hi2.data_ptr(),
+                                          lo2.data_ptr(), None, E, Mr, E, K, _stream()), "tc_gemm_residual_split")
+    assert torch.equal(hi2, hi) and torch.equal(lo2, lo)
     want16 = want.to(torch.bfloat16)
     if K < 512:
         assert torch.equal(hi, want16)
