@@ -201,6 +201,22 @@ int tc_codon_stats(const uint8_t *bases, const uint8_t *ref_bases, const int32_t
                    const uint8_t *codon_flags, int32_t *counts, int n_seq, void *stream);
 
 /*
+ * %MinMax profile of decoded coding sequences (evaluation/minmax.py:9-79): for every codon position i of a
+ * sequence with i + window <= its length, the mean actual / maximal / minimal / average usage frequency of the
+ * window's codons and from them the signed percentage; the sums run in the host loop's order in f64, so the
+ * values equal the reference's bit for bit.  Positions a window does not fit (the reference pads its list with
+ * None there) hold NaN.  A window over amino acids that all have one codon divides by zero (the reference raises
+ * ZeroDivisionError there) and holds the IEEE result.  A letter outside ACGTU or a codon absent from the table
+ * ORs 1 into *status (zero it first) and leaves NaN in the windows that cover it.
+ *   bases      uint8 [3 * n_codons]     codon_off int32 [n_seq+1] (as tc_codon_stats)
+ *   tables     f64 [4,64]               rows: frequency of the codon, and the maximum, minimum and mean frequency
+ *                                       among its amino acid's codons (index 16a+4b+c over A,C,G,T|U); NaN = absent
+ *   out        f64 [n_codons]           status int32 [1]
+ */
+int tc_codon_minmax(const uint8_t *bases, const int32_t *codon_off, const double *tables, int window,
+                    double *out, int32_t *status, int n_seq, long n_codons, void *stream);
+
+/*
  * Mean cross-entropy with ignore_index = -100 over rows of thin logits, forward and
  * (optionally) gradient.  Replaces nn.CrossEntropyLoss(reduction='mean',
  * ignore_index=-100) of pretraining.py:54-55,109-112,124-127.

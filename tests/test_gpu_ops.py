@@ -499,3 +499,31 @@ def test_codon_stats_kernel_equals_host_metrics(golden_dir):
         assert m5["cfd"][i] == pytest.approx(c["cfd_05"], rel=1e-12)
     with pytest.raises(KeyError):
         EV.device_metrics(up(["ATGNNN"]), torch.tensor([0, 2], dtype=torch.int32))
+
+
+def test_minmax_kernel_equals_the_reference_lists_bit_for_bit(golden_dir):
+    """%MinMax on the device (tc_codon_minmax) against the lists evaluation/minmax.py:9-79 itself produced for the
+    fixture's sequences (window 18 and 5): same f64 operations in the same order, so equality is exact; the tail a
+    window does not fit is None as in the reference."""
+    import json
+    import os
+    from transcodon_amd import evaluation as EV
+    with open(os.path.join(golden_dir, "evaluation.json")) as fh:
+        g = json.load(fh)
+    usage = EV.CodonUsage({k: (v[0], v[1]) for k, v in g["codon_frequencies"].items()})
+    cases = [c for c in g["cases"] if len(c["dna"]) % 3 == 0]
+    assert len(cases) >= 5 and max(len(c["dna"]) for c in cases) >= 900
+    dna = [c["dna"] for c in cases]
+    off = torch.from_numpy(np.concatenate([[0], np.cumsum([len(d) // 3 for d in dna])]).astype(np.int32))
+    up = lambda strs: torch.frombuffer(bytearray("".join(strs).encode()), dtype=torch.uint8).to(DEV)
+    for window, key in ((18, "minmax"), (5, "minmax_w5")):
+        got = EV.device_min_max(up(dna), off, usage, window_size=window)
+        n_exact = 0
+        for c, lst in zip(cases, got):
+            assert lst == c[key], (len(c["dna"]), window)
+            n_exact += sum(v is not None for v in lst)
+        assert n_exact > 300
+    # RNA letters count as DNA; a letter outside the alphabet is an error, as on the host
+    assert EV.device_min_max(up([dna[-1].replace("T", "U")]), off[-2:] - off[-2], usage) == [cases[-1]["minmax"]]
+    with pytest.raises(KeyError):
+        EV.device_min_max(up(["ATGNNN" * 10]), torch.tensor([0, 20], dtype=torch.int32), usage)

@@ -113,3 +113,43 @@ def test_pretrain_cli_logs_reference_metric_names(tmp_path, capsys):
     assert sorted(os.listdir(tmp_path / "run")) == ["latest-2.ckpt", "latest-2.ckpt.optim", "latest-4.ckpt",
                                                     "latest-4.ckpt.optim", "metrics.jsonl"]
     assert lines[0]["event"] == "start" and lines[-1]["event"] == "done"
+
+
+def test_fine_tuning_starts_from_weights_only(tmp_path):
+    """--pretrained_model (fintune.py:246-248): the file's tensors replace the initial weights, keys it lacks keep
+    theirs, the optimiser and the step count start fresh; the first step's loss is the trained model's, not a new one's."""
+    from safetensors.torch import save_file
+    from transcodon_amd import checkpoint
+    args = _args(tmp_path)
+    ds = SequenceDataset.synthetic(args.synthetic, seed=args.seed, max_codons=args.synthetic_max_codons, n_species=16)
+    tr = pretrain.Trainer(args, ds, torch.device(DEV))
+    first = tr.train_step()["train_mask_loss"]
+    for _ in range(15):
+        tr.train_step()
+    weights = str(tmp_path / "trained.safetensors")
+    checkpoint.save(tr.model, weights)
+    # a second file without the structure head: those keys must be reported missing and stay at their initial values
+    partial = {k: v for k, v in checkpoint.read_state_dict(weights).items() if "struct" not in k.lower()}
+    assert len(partial) < len(checkpoint.read_state_dict(weights))
+    save_file({k: v.clone() for k, v in partial.items()}, str(tmp_path / "partial.safetensors"))
+
+    tr2 = pretrain.Trainer(_args(tmp_path, ["--seed", "5"]), ds, torch.device(DEV))
+    before = {k: v.detach().clone() for k, v in tr2.model.state_dict().items()}
+    missing, unexpected = tr2.init_from(str(tmp_path / "partial.safetensors"))
+    assert unexpected == [] and missing and all("struct" in k.lower() for k in missing)
+    after = tr2.model.state_dict()
+    trained = tr.model.state_dict()
+    for k in after:
+        if k in missing:
+            assert torch.equal(after[k], before[k]), k
+        else:
+            assert torch.equal(after[k], trained[k]), k
+    assert (tr2.global_step, tr2.micro_step, tr2.opt.step_count) == (0, 0, 0)
+    assert float(tr2.opt.exp_avg.abs().max()) == 0.0
+    rec = tr2.train_step()
+    assert rec["step"] == 1 and rec["lr"] == pytest.approx(2e-3 * 1 / 4)
+    assert rec["train_mask_loss"] < first - 0.3, (rec, first)
+    # the command line refuses the two starting points together
+    with pytest.raises(SystemExit):
+        pretrain.main(["--synthetic", "8", "--resume", "a.ckpt", "--pretrained_model", "b.safetensors",
+                       "--output_dir", str(tmp_path / "x")])

@@ -95,6 +95,7 @@ _SIGNATURES = {
                                      C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "tc_codon_decode": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "tc_codon_stats": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp]),
+    "tc_codon_minmax": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_long, vp]),
     "tc_ce_loss_fwd_bwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp]),
     "tc_mean_pool": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "tc_gemm_train": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int,

@@ -712,7 +712,67 @@ __global__ __launch_bounds__(256) void codon_stats_kernel(const uint8_t *__restr
     if (threadIdx.x < 4) out[4 * s + threadIdx.x] = acc[threadIdx.x];
 }
 
+// ---- %MinMax windows of decoded bases -------------------------------------------------------------
+// One thread per codon position.  Position i of a sequence of n codons with i + window <= n sums the four
+// table values of codons i .. i + window - 1 in that order in f64, as the host loop does, so the value
+// equals the host's to the last bit; every other position (the tail a window does not fit) gets NaN.
+// A letter outside ACGTU, or a codon whose table entry is NaN, sets *status to 1 (and the windows that cover it
+// hold NaN); a window whose amino acids all have a single codon divides by zero and holds what IEEE gives.
+__global__ __launch_bounds__(256) void codon_minmax_kernel(const uint8_t *__restrict__ bases,
+                                                           const int32_t *__restrict__ off,
+                                                           const double *__restrict__ tab, int window, int n_seq,
+                                                           long n_codons, double *__restrict__ out,
+                                                           int32_t *__restrict__ status) {
+    __shared__ double t[4 * 64];
+    for (int e = threadIdx.x; e < 256; e += 256) t[e] = tab[e];
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_codons) return;
+    // the sequence that owns codon i: last s with off[s] <= i
+    int lo = 0, hi = n_seq;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((long)off[mid] <= i) lo = mid; else hi = mid;
+    }
+    const long last = off[lo + 1];
+    const double nan = __builtin_nan("");
+    if (i + window > last) { out[i] = nan; return; }
+    double actual = 0.0, mx = 0.0, mn = 0.0, avg = 0.0;
+    bool bad = false;
+    for (int w = 0; w < window; ++w) {
+        int idx = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint8_t c = bases[3L * (i + w) + j];
+            const int v = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : (c == 'T' || c == 'U') ? 3 : -1;
+            bad |= v < 0;
+            idx = idx * 4 + (v < 0 ? 0 : v);
+        }
+        bad |= t[idx] != t[idx];
+        actual += t[idx];
+        mx += t[64 + idx];
+        mn += t[128 + idx];
+        avg += t[192 + idx];
+    }
+    const double ws = (double)window;
+    actual /= ws; mx /= ws; mn /= ws; avg /= ws;
+    const double pmax = ((actual - avg) / (mx - avg)) * 100.0;
+    const double pmin = ((avg - actual) / (avg - mn)) * 100.0;
+    out[i] = bad ? nan : (pmax >= 0.0 ? pmax : -pmin);
+    if (bad) atomicOr(status, 1);
+}
+
 }  // namespace
+
+extern "C" int tc_codon_minmax(const uint8_t *bases, const int32_t *codon_off, const double *tables, int window,
+                               double *out, int32_t *status, int n_seq, long n_codons, void *stream) {
+    TC_REQUIRE(bases && codon_off && tables && out && status && n_seq > 0 && n_codons > 0 && window > 0,
+               "tc_codon_minmax: bad arguments");
+    TC_LAUNCH(codon_minmax_kernel, dim3((unsigned)((n_codons + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+              bases, codon_off, tables, window, n_seq, n_codons, out, status);
+    TC_CHECK_LAUNCH("tc_codon_minmax");
+    return TC_OK;
+}
 
 extern "C" int tc_codon_stats(const uint8_t *bases, const uint8_t *ref_bases, const int32_t *codon_off,
                               const uint8_t *codon_flags, int32_t *counts, int n_seq, void *stream) {

@@ -122,3 +122,34 @@ def device_metrics(bases, codon_off, ref_bases=None, usage: Optional[CodonUsage]
     return {"gc": c[:, 0] / (3 * n) * 100,
             "recovery": None if ref is None else c[:, 1] / n,
             "cfd": None if flags is None else c[:, 2] / n * 100}
+
+
+def device_min_max(bases, codon_off, usage: CodonUsage, window_size: int = 18):
+    """%MinMax profiles of many decoded sequences at once on the GPU (tc_codon_minmax): ``bases`` uint8
+    [3 * n_codons] (ASCII, CUDA tensor), ``codon_off`` int32 [n_seq+1].  Returns one list per sequence in the
+    reference's form (minmax.py:31-79): len - window_size + 1 floats, then window_size // 2 None entries; the
+    floats equal get_min_max_percentage's bit for bit (same f64 operations in the same order)."""
+    import torch
+    from . import _lib
+    if not bases.is_cuda:
+        raise _lib.HipLibraryError("device_min_max needs the bases on the GPU (use min_max_percentage on the host)")
+    off = codon_off.to(device=bases.device, dtype=torch.int32).contiguous()
+    n_seq = off.numel() - 1
+    off_h = off.cpu().numpy()
+    n_codons = int(off_h[-1])
+    tables = torch.from_numpy(np.stack([usage.freq, usage.max, usage.min, usage.avg]).astype(np.float64)).to(bases.device)
+    out = torch.empty(max(n_codons, 1), dtype=torch.float64, device=bases.device)
+    status = torch.zeros(1, dtype=torch.int32, device=bases.device)
+    if n_codons:
+        _lib.check(_lib.load().tc_codon_minmax(bases.contiguous().data_ptr(), off.data_ptr(), tables.data_ptr(),
+                                               int(window_size), out.data_ptr(), status.data_ptr(), n_seq, n_codons,
+                                               torch.cuda.current_stream().cuda_stream), "tc_codon_minmax")
+    vals = out.cpu().numpy()
+    if int(status.item()):
+        raise KeyError("sequence contains a letter outside ACGTU or a codon missing from the usage table")
+    res = []
+    for s in range(n_seq):
+        a, b = int(off_h[s]), int(off_h[s + 1])
+        n = max(b - a - window_size + 1, 0)
+        res.append([float(x) for x in vals[a:a + n]] + [None] * int(window_size / 2))
+    return res

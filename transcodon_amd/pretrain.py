@@ -58,6 +58,9 @@ def build_parser():
     p.add_argument("--val_check_interval", type=int, default=1000, help="optimiser steps between validation passes")
     p.add_argument("--limit_val_batches", type=float, default=0.1)
     p.add_argument("--resume", type=str, default=None, help="latest-<step>.ckpt to continue from")
+    p.add_argument("--pretrained_model", type=str, default=None,
+                   help="start from these weights (.safetensors / .ckpt) with a fresh optimiser and step count; keys the "
+                        "file lacks keep their initial values (fintune.py:246-248)")
     p.add_argument("--precision", choices=("bf16", "fp32"), default="bf16")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--synthetic", type=int, default=0, help="use N random coding sequences instead of --train_data")
@@ -196,6 +199,12 @@ class Trainer:
                    path + ".optim")
         return path
 
+    def init_from(self, path):
+        """Weights only, non-strict, optimiser state and step count untouched (fintune.py:246-248).  Returns the
+        (missing, unexpected) key lists of the load."""
+        res = checkpoint.load_into(self.model, path, strict=False)
+        return list(res.missing_keys), list(res.unexpected_keys)
+
     def load(self, path):
         checkpoint.load_into(self.model, path)
         st = torch.load(path + ".optim", map_location="cpu", weights_only=True)
@@ -215,6 +224,8 @@ class _Null:
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if args.resume and args.pretrained_model:
+        raise SystemExit("--resume continues a run with its own weights; --pretrained_model starts a new one: give one of them")
     world, rank, dev = _dist_setup()
     if args.synthetic:
         ds = SequenceDataset.synthetic(args.synthetic, seed=args.seed, max_codons=args.synthetic_max_codons,
@@ -224,6 +235,11 @@ def main(argv=None):
     tr = Trainer(args, ds, dev, world, rank)
     if args.resume:
         tr.load(args.resume)
+    elif args.pretrained_model:
+        missing, unexpected = tr.init_from(args.pretrained_model)
+        if rank == 0:
+            print(json.dumps({"event": "init_from", "path": args.pretrained_model, "missing_keys": missing,
+                              "unexpected_keys": unexpected}), flush=True)
     log = None
     if rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)
