@@ -252,6 +252,15 @@ int tc_transpose_cast(int in_dtype, int out_dtype, const void *in, int ld_in, vo
                       void *out_rowmajor, int ld_rm, float *colsum, int M, int N, void *stream);
 
 /*
+ * Many dense transposes in one launch: dst[e] [cols, rows] = src[e] [rows, cols]^T for e < n (host arrays of device
+ * pointers and sizes; rows and cols multiples of 64, 16-byte aligned, no overlap).  The backward pass transposes
+ * every weight matrix this way once (the x.t() of F.linear's data gradient, taken by autograd for
+ * modules.py:96-104, multihead_attention.py:139-148): one launch instead of one per matrix.
+ */
+int tc_transpose_batch(int dtype, int n, const void *const *src, void *const *dst, const int *rows,
+                       const int *cols, void *stream);
+
+/*
  * Weight-gradient product on row-major bf16 operands, no transposed copies:
  *   out[s][i, j] = sum over the s-th part of the rows m of A[m, i] * B[m, j]     (f32, s < splits)
  * A [M, lda] is the output gradient dY, B [M, ldb] the layer input X, so that summing the

@@ -415,3 +415,30 @@ def test_store_backed_model_sees_weights_written_through_parameters(tmp_path):
         np.testing.assert_allclose((shifted["struct_label_output"] - again["struct_label_output"]).cpu().numpy(),
                                    1.0, atol=1e-4)
         assert not torch.equal(moved["logits"], again["logits"])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_batched_transposes_equal_torch(dtype):
+    """tc_transpose_batch: matrices of the encoder's shapes (and more than one launch's worth of them) against .t()."""
+    import ctypes as C
+    from transcodon_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    shapes = [(768, 768), (2304, 768), (3072, 768), (768, 3072), (64, 64), (128, 192)] * 9      # 54 > one launch's 48
+    src = [torch.randn(r, c, device=DEV, generator=g).to(dtype) for r, c in shapes]
+    dst = [torch.full((c, r), 7.0, device=DEV, dtype=dtype) for r, c in shapes]
+    n = len(shapes)
+    P = C.c_void_p * n
+    I = C.c_int * n
+    rc = lib.tc_transpose_batch(_lib.TC_BF16 if dtype == torch.bfloat16 else _lib.TC_F32, n,
+                                P(*[t.data_ptr() for t in src]), P(*[t.data_ptr() for t in dst]),
+                                I(*[r for r, _ in shapes]), I(*[c for _, c in shapes]),
+                                torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "tc_transpose_batch")
+    for a, b in zip(src, dst):
+        assert torch.equal(b, a.t())
+    # sizes that are not multiples of 64 are refused before anything is launched
+    bad = lib.tc_transpose_batch(_lib.TC_F32, 1, (C.c_void_p * 1)(src[0].data_ptr()),
+                                 (C.c_void_p * 1)(dst[0].data_ptr()), (C.c_int * 1)(100), (C.c_int * 1)(64),
+                                 torch.cuda.current_stream().cuda_stream)
+    assert bad != 0 and b"multiples of 64" in lib.tc_last_error()

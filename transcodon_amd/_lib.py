@@ -100,6 +100,7 @@ _SIGNATURES = {
     "tc_mean_pool": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "tc_gemm_train": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int, vp]),
+    "tc_transpose_batch": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "tc_transpose_cast": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp,
                                     C.c_int, C.c_int, vp]),
     "tc_gemm_tn": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -37,7 +37,7 @@ struct TrainWs {
     int ld_f;            // row stride of every [M,F] activation: F + 64
     void *tr_a;          // dtype [max(F,3E), Mp]
     void *tr_b;          // dtype [max(F,E), Mp]
-    void *wt;            // dtype transposed weight, max(F*E, 3E*E)
+    char *wt_all;        // dtype, every weight matrix transposed (one launch per backward pass): wt_of()
     float *slabs;        // split-K partial weight gradients
     float *delta;        // f32 [B,H,T]
     size_t slab_floats;
@@ -105,7 +105,7 @@ TrainWs carve(const tc_encoder_desc *d, int B, int T, char *base) {
     w.wide = take(M * wide * esz);
     w.tr_a = take(wide * Mp * esz);
     w.tr_b = take((F > E ? F : E) * Mp * esz);
-    w.wt = take((F > 3 * E ? F : 3 * E) * E * esz);
+    w.wt_all = take(((size_t)d->num_layers * (4 * E * E + 2 * E * F) + 2 * E * E) * esz);
     size_t sf = 0;
     const size_t shapes[4][2] = {{E, F}, {F, E}, {3 * E, E}, {E, E}};
     for (auto &sh : shapes) {
@@ -172,9 +172,40 @@ int linear_wgrad(const tc_encoder_desc *d, TrainWs &w, int in_dt, const void *dy
     return TC_OK;
 }
 
-// wt[n_in, n_out] = W[n_out, n_in]^T : the "weight" operand of the data-gradient GEMM dX = dY W
-int transpose_weight(const tc_encoder_desc *d, TrainWs &w, const void *W, int n_out, int n_in, void *stream) {
-    return tc_transpose_cast(d->dtype, d->dtype, W, n_in, w.wt, n_out, nullptr, 0, nullptr, n_out, n_in, stream);
+// Transposed weights, wt[n_in, n_out] = W[n_out, n_in]^T: the "weight" operand of the data-gradient products dX = dY W.
+// Layer l keeps q/k/v, out-proj, fc1, fc2 in this order; the two head dense matrices follow the last layer.
+enum { WT_QKV = 0, WT_O = 1, WT_FC1 = 2, WT_FC2 = 3 };
+void *wt_of(const tc_encoder_desc *d, const TrainWs &w, int layer, int which) {
+    const size_t E = d->E, F = d->F, esz = d->dtype == TC_BF16 ? 2 : 4;
+    const size_t per_layer = 4 * E * E + 2 * E * F;
+    const size_t in_layer[4] = {0, 3 * E * E, 4 * E * E, 4 * E * E + E * F};
+    return w.wt_all + ((size_t)layer * per_layer + in_layer[which]) * esz;
+}
+void *wt_of_head(const tc_encoder_desc *d, const TrainWs &w, int head) {
+    const size_t E = d->E, F = d->F, esz = d->dtype == TC_BF16 ? 2 : 4;
+    return w.wt_all + ((size_t)d->num_layers * (4 * E * E + 2 * E * F) + (size_t)head * E * E) * esz;
+}
+// one launch (per 48 matrices) for all of them
+int transpose_weights(const tc_encoder_desc *d, const TrainWs &w, void *stream) {
+    constexpr int kMost = 4 * kMaxLayers + 2;
+    static_assert(kMost <= 512, "descriptor arrays on the stack");
+    const void *src[kMost];
+    void *dst[kMost];
+    int rows[kMost], cols[kMost];
+    const int E = d->E, F = d->F;
+    const size_t esz = d->dtype == TC_BF16 ? 2 : 4;
+    int n = 0;
+    auto add = [&](const void *W, void *wt, int n_out, int n_in) { src[n] = W; dst[n] = wt; rows[n] = n_out; cols[n] = n_in; ++n; };
+    for (int h = 0; h < 2; ++h)       // the backward pass starts with the heads
+        add(static_cast<const char *>(d->w_heads) + (size_t)h * E * E * esz, wt_of_head(d, w, h), E, E);
+    for (int l = d->num_layers - 1; l >= 0; --l) {
+        const tc_layer_weights &lw = d->layers[l];
+        add(lw.w_fc2, wt_of(d, w, l, WT_FC2), E, F);
+        add(lw.w_fc1, wt_of(d, w, l, WT_FC1), F, E);
+        add(lw.w_o, wt_of(d, w, l, WT_O), E, E);
+        add(lw.w_qkv, wt_of(d, w, l, WT_QKV), 3 * E, E);
+    }
+    return tc_transpose_batch(d->dtype, n, src, dst, rows, cols, stream);
 }
 
 }  // namespace
@@ -281,8 +312,6 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
         return TC_ENOSPC;
     }
     const int M = B * T, E = d->E, F = d->F, dt = d->dtype;
-    const size_t esz = dt == TC_BF16 ? 2 : 4;
-    const char *w_heads = static_cast<const char *>(d->w_heads);
     float *dx = w.t1;    // gradient of the residual stream, walked down the layers
 
     // ---- heads: d_hf accumulated in t0 ----
@@ -296,6 +325,8 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
         {dstruct_logits, w.g_st, w.u_st, d->st_ln_g, d->st_ln_b, d->st_w, g->st_ln_g, g->st_ln_b, g->st_w, g->st_bias,
          d->n_struct, (size_t)E * E},
     };
+    // every data-gradient product below reads its weight matrix transposed
+    TC_TRY(transpose_weights(d, w, stream));
     bool have_dhf = false;
     for (const Head &h : heads) {
         if (!h.dl) continue;
@@ -307,12 +338,12 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
         TC_TRY(tc_dgelu(dt, w.t1, h.u, w.dyb, (long)M * E, stream));
         TC_TRY(linear_wgrad(d, w, dt, w.dyb, E, nullptr, w.hf, E, M, E, E, g->w_heads + h.wofs, g->b_heads + (h.wofs ? E : 0),
                             stream));
-        TC_TRY(transpose_weight(d, w, w_heads + h.wofs * esz, E, E, stream));
+        const void *wt = wt_of_head(d, w, h.wofs ? 1 : 0);
         if (!have_dhf)
-            TC_TRY(tc_gemm_train(dt, TC_EPI_PLAIN_F32, w.dyb, E, w.wt, nullptr, nullptr, w.t0, nullptr, E, M, E, E, 1,
+            TC_TRY(tc_gemm_train(dt, TC_EPI_PLAIN_F32, w.dyb, E, wt, nullptr, nullptr, w.t0, nullptr, E, M, E, E, 1,
                                  stream));
         else
-            TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.dyb, E, w.wt, nullptr, w.t0, w.t0, E, M, E, E, 0.f, nullptr,
+            TC_TRY(tc_gemm(dt, TC_EPI_BIAS_RESIDUAL, w.dyb, E, wt, nullptr, w.t0, w.t0, E, M, E, E, 0.f, nullptr,
                            nullptr, 0, 0, stream));
         have_dhf = true;
     }
@@ -335,16 +366,14 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
             TC_TRY(linear_wgrad(d, w, TC_BF16, w.dyb, E, nullptr, sv.mid, w.ld_f, M, E, F, lg.w_fc2, nullptr, stream));
         else
             TC_TRY(linear_wgrad(d, w, TC_F32, dx, E, w.dyb, sv.mid, w.ld_f, M, E, F, lg.w_fc2, lg.b_fc2, stream));
-        TC_TRY(transpose_weight(d, w, lw.w_fc2, E, F, stream));
         // fc1's bias gradient is summed in the epilogue that produces d_u (bf16 mode)
-        TC_TRY(tc_gemm_train(dt, TC_EPI_DGELU, w.dyb, E, w.wt, nullptr, sv.u, w.wide, fuse ? lg.b_fc1 : nullptr, w.ld_f, M,
+        TC_TRY(tc_gemm_train(dt, TC_EPI_DGELU, w.dyb, E, wt_of(d, w, l, WT_FC2), nullptr, sv.u, w.wide, fuse ? lg.b_fc1 : nullptr, w.ld_f, M,
                              F, E, 1, stream));
         TC_TRY(linear_wgrad(d, w, dt, w.wide, w.ld_f, nullptr, sv.h2, E, M, F, E, lg.w_fc1, fuse ? nullptr : lg.b_fc1,
                             stream));
-        TC_TRY(transpose_weight(d, w, lw.w_fc1, F, E, stream));
         // the gradient handed to a LayerNorm comes out of the product in the compute type (bf16: what a
         // bf16 Linear returns under autocast), half the bytes for the product to write and the LayerNorm to read
-        TC_TRY(tc_gemm(dt, TC_EPI_BIAS, w.wide, w.ld_f, w.wt, nullptr, nullptr, w.t0, E, M, E, F, 0.f, nullptr, nullptr, 0,
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS, w.wide, w.ld_f, wt_of(d, w, l, WT_FC1), nullptr, nullptr, w.t0, E, M, E, F, 0.f, nullptr, nullptr, 0,
                        0, stream));
         TC_TRY(tc_layernorm_bwd_dy(TC_F32, sv.x_mid, E, lw.ln2_g, dt, w.t0, E, dx, 1, lg.ln2_g, lg.ln2_b,
                                    fuse ? w.dyb : nullptr, fuse ? lg.b_o : nullptr, M, E, d->ln_eps, stream));
@@ -353,15 +382,13 @@ extern "C" int tc_encoder_backward_notify(const tc_encoder_desc *d, const tc_enc
             TC_TRY(linear_wgrad(d, w, TC_BF16, w.dyb, E, nullptr, sv.ao, E, M, E, E, lg.w_o, nullptr, stream));
         else
             TC_TRY(linear_wgrad(d, w, TC_F32, dx, E, w.dyb, sv.ao, E, M, E, E, lg.w_o, lg.b_o, stream));
-        TC_TRY(transpose_weight(d, w, lw.w_o, E, E, stream));
         void *d_ao = w.tr_b;      // free between weight-gradient products
-        TC_TRY(tc_gemm(dt, TC_EPI_BIAS, w.dyb, E, w.wt, nullptr, nullptr, d_ao, E, M, E, E, 0.f, nullptr, nullptr, 0, 0,
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS, w.dyb, E, wt_of(d, w, l, WT_O), nullptr, nullptr, d_ao, E, M, E, E, 0.f, nullptr, nullptr, 0, 0,
                        stream));
         TC_TRY(tc_attn_bwd(dt, sv.qkv, 3 * E, w.words, sv.ao, d_ao, sv.lse, w.delta, w.wide, 3 * E, lw.rope_cos,
                            lw.rope_sin, 0.125f, B, T, d->H, 64, stream));
         TC_TRY(linear_wgrad(d, w, dt, w.wide, 3 * E, nullptr, sv.h1, E, M, 3 * E, E, lg.w_qkv, lg.b_qkv, stream));
-        TC_TRY(transpose_weight(d, w, lw.w_qkv, 3 * E, E, stream));
-        TC_TRY(tc_gemm(dt, TC_EPI_BIAS, w.wide, 3 * E, w.wt, nullptr, nullptr, w.t0, E, M, E, 3 * E, 0.f, nullptr, nullptr,
+        TC_TRY(tc_gemm(dt, TC_EPI_BIAS, w.wide, 3 * E, wt_of(d, w, l, WT_QKV), nullptr, nullptr, w.t0, E, M, E, 3 * E, 0.f, nullptr, nullptr,
                        0, 0, stream));
         const bool below = fuse && l > 0;    // layer 0 hands dx to the embedding backward only
         TC_TRY(tc_layernorm_bwd_dy(TC_F32, sv.x_in, E, lw.ln1_g, dt, w.t0, E, dx, 1, lg.ln1_g, lg.ln1_b,

@@ -59,6 +59,57 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI *__restrict__ i
     }
 }
 
+// ---- many transposes in one launch ---------------------------------------------------------------
+// The data-gradient products read every weight matrix transposed; the matrices change once per optimiser
+// step, so all of them are transposed by one launch per backward pass instead of one small launch each
+// (a 768 x 768 matrix is 144 tiles: such launches are latency, not bandwidth).  Entry e: src [rows, cols]
+// dense -> dst [cols, rows] dense, rows and cols multiples of 64; 64 x 64 tiles, 16 bytes per lane both ways.
+constexpr int kTbMax = 48;
+struct TransposeBatch {
+    const void *src[kTbMax];
+    void *dst[kTbMax];
+    int rows[kTbMax], cols[kTbMax];
+    int first_tile[kTbMax + 1];
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const TransposeBatch b) {
+    constexpr int V = 16 / sizeof(T);              // elements per 16-byte piece
+    constexpr int CPR = 64 / V;                    // pieces per tile row
+    __shared__ T tile[64][64 + 4 / sizeof(T)];     // row stride 4 bytes past 64 elements
+    int e = 0;
+    while (e + 1 < b.n && (int)blockIdx.x >= b.first_tile[e + 1]) ++e;
+    const int local = blockIdx.x - b.first_tile[e];
+    const int rows = b.rows[e], cols = b.cols[e];
+    const int tiles_c = cols >> 6;
+    const int r0 = (local / tiles_c) << 6, c0 = (local % tiles_c) << 6;
+    const T *src = static_cast<const T *>(b.src[e]);
+    T *dst = static_cast<T *>(b.dst[e]);
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+#pragma unroll
+    for (int i = 0; i < CPR * 64 / 256; ++i) {
+        const int piece = threadIdx.x + i * 256;
+        const int r = piece / CPR, c = piece % CPR;
+        const u4 v = *reinterpret_cast<const u4 *>(src + (long)(r0 + r) * cols + c0 + c * V);
+        T tmp[V];
+        __builtin_memcpy(tmp, &v, 16);
+#pragma unroll
+        for (int j = 0; j < V; ++j) tile[r][c * V + j] = tmp[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CPR * 64 / 256; ++i) {
+        const int piece = threadIdx.x + i * 256;
+        const int n = piece / CPR, m = piece % CPR;      // output row (input column), piece of V input rows
+        T tmp[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) tmp[j] = tile[m * V + j][n];
+        u4 v;
+        __builtin_memcpy(&v, tmp, 16);
+        *reinterpret_cast<u4 *>(dst + (long)(c0 + n) * rows + r0 + m * V) = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs,
                                                            float *__restrict__ out, int S, long n,
                                                            int accumulate) {
@@ -498,6 +549,35 @@ extern "C" int tc_transpose_cast(int in_dtype, int out_dtype, const void *in, in
                            static_cast<const uint16_t *>(in), (long)ld_in, static_cast<uint16_t *>(out_t), (long)ldt,
                            static_cast<uint16_t *>(out_rowmajor), (long)ld_rm, colsum, M, N);
     TC_CHECK_LAUNCH("tc_transpose_cast");
+    return TC_OK;
+}
+
+extern "C" int tc_transpose_batch(int dtype, int n, const void *const *src, void *const *dst, const int *rows,
+                                  const int *cols, void *stream) {
+    TC_REQUIRE(dtype == TC_F32 || dtype == TC_BF16, "tc_transpose_batch: bad dtype %d", dtype);
+    TC_REQUIRE(n > 0 && src && dst && rows && cols, "tc_transpose_batch: bad arguments");
+    for (int e = 0; e < n; ++e)
+        TC_REQUIRE(src[e] && dst[e] && rows[e] > 0 && cols[e] > 0 && rows[e] % 64 == 0 && cols[e] % 64 == 0 &&
+                       tc_aligned16(src[e]) && tc_aligned16(dst[e]) && (long)(rows[e] >> 6) * (cols[e] >> 6) < (1L << 24),
+                   "tc_transpose_batch: entry %d: %d x %d (multiples of 64, 16-byte aligned, dense)", e, rows[e], cols[e]);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int e0 = 0; e0 < n; e0 += kTbMax) {
+        TransposeBatch b{};
+        b.n = n - e0 < kTbMax ? n - e0 : kTbMax;
+        int tiles = 0;
+        for (int e = 0; e < b.n; ++e) {
+            b.src[e] = src[e0 + e];
+            b.dst[e] = dst[e0 + e];
+            b.rows[e] = rows[e0 + e];
+            b.cols[e] = cols[e0 + e];
+            b.first_tile[e] = tiles;
+            tiles += (rows[e0 + e] >> 6) * (cols[e0 + e] >> 6);
+        }
+        b.first_tile[b.n] = tiles;
+        if (dtype == TC_BF16) TC_LAUNCH(transpose_batch_kernel<uint16_t>, dim3((unsigned)tiles), dim3(256), 0, s, b);
+        else TC_LAUNCH(transpose_batch_kernel<float>, dim3((unsigned)tiles), dim3(256), 0, s, b);
+        TC_CHECK_LAUNCH("tc_transpose_batch");
+    }
     return TC_OK;
 }
 
