@@ -437,34 +437,70 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const uint16_t *__restri
     // LDS: fragment (step, plane) of G at ((step * 2 + plane) * 64 + lane) * 16; then s[16], c[16]
     float *sc = reinterpret_cast<float *>(smem + steps * 2 * 1024);
     {
+        // Every load of this set-up is a 16-byte load, and a group of them (four k steps, or one output's row of
+        // W with gamma and beta) is in flight at once: the set-up costs a handful of memory latencies per
+        // workgroup instead of one per k step and column, and stays within the registers of the row loop.
         const int i = lane & 15, kg = lane >> 4;     // operand row (output) i, k group
-        for (int st = wid; st < steps; st += 4) {
-            const int k0 = st * 32 + kg * 8;
-            u32x4 hi = {0u, 0u, 0u, 0u}, lo = hi;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {       // E <= 1024: at most 8 steps per wave
+            f32x4 gv[4][2], wv[4][2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float a = 0.f, b = 0.f;
-                if (i < V) {
-                    a = gamma[k0 + 2 * e] * W[(long)i * E + k0 + 2 * e];
-                    b = gamma[k0 + 2 * e + 1] * W[(long)i * E + k0 + 2 * e + 1];
-                } else if (i == V) {
-                    a = b = 1.0f;
+            for (int u = 0; u < 4; ++u) {
+                const int st = wid + 4 * (4 * half + u);
+                if (st < steps) {
+                    const int k0 = st * 32 + kg * 8;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        gv[u][h] = *reinterpret_cast<const f32x4 *>(gamma + k0 + 4 * h);
+                        wv[u][h] = i < V ? *reinterpret_cast<const f32x4 *>(W + (long)i * E + k0 + 4 * h)
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                 }
-                hi[e] = tc_pack_bf16(a, b);
-                lo[e] = tc_pack_bf16(a - tc_bf16_lo(hi[e]), b - tc_bf16_hi(hi[e]));
             }
-            *reinterpret_cast<u32x4 *>(smem + ((st * 2 + 0) * 64 + lane) * 16) = hi;
-            *reinterpret_cast<u32x4 *>(smem + ((st * 2 + 1) * 64 + lane) * 16) = lo;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int st = wid + 4 * (4 * half + u);
+                if (st < steps) {
+                    u32x4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = gv[u][e >> 1][(2 * e) & 3] * wv[u][e >> 1][(2 * e) & 3];
+                        float b = gv[u][e >> 1][(2 * e + 1) & 3] * wv[u][e >> 1][(2 * e + 1) & 3];
+                        if (i == V) a = b = 1.0f;
+                        hi[e] = tc_pack_bf16(a, b);
+                        lo[e] = tc_pack_bf16(a - tc_bf16_lo(hi[e]), b - tc_bf16_hi(hi[e]));
+                    }
+                    *reinterpret_cast<u32x4 *>(smem + ((st * 2 + 0) * 64 + lane) * 16) = hi;
+                    *reinterpret_cast<u32x4 *>(smem + ((st * 2 + 1) * 64 + lane) * 16) = lo;
+                }
+            }
         }
         // s and c of output o by wave o & 3 (sums of the values the MFMAs multiply: hi + lo)
+#pragma unroll 1
         for (int o = wid; o < V; o += 4) {
+            f32x4 sg[4], sb[4], sw[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = (c * 64 + lane) * 4;
+                if (k < E) {
+                    sg[c] = *reinterpret_cast<const f32x4 *>(gamma + k);
+                    sb[c] = *reinterpret_cast<const f32x4 *>(beta + k);
+                    sw[c] = *reinterpret_cast<const f32x4 *>(W + (long)o * E + k);
+                }
+            }
             float s1 = 0.f, c1 = 0.f;
-            for (int k = lane; k < E; k += 64) {
-                const float gw = gamma[k] * W[(long)o * E + k];
-                const uint32_t h = tc_pack_bf16(gw, 0.f);
-                const uint32_t l = tc_pack_bf16(gw - tc_bf16_lo(h), 0.f);
-                s1 += tc_bf16_lo(h) + tc_bf16_lo(l);
-                c1 += beta[k] * W[(long)o * E + k];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if ((c * 64 + lane) * 4 < E) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gw = sg[c][e] * sw[c][e];
+                        const uint32_t h = tc_pack_bf16(gw, 0.f);
+                        const uint32_t l = tc_pack_bf16(gw - tc_bf16_lo(h), 0.f);
+                        s1 += tc_bf16_lo(h) + tc_bf16_lo(l);
+                        c1 += sb[c][e] * sw[c][e];
+                    }
+                }
             }
             s1 = tc_wave_sum(s1);
             c1 = tc_wave_sum(c1);
@@ -978,7 +1014,8 @@ extern "C" int tc_head_logits_fwd(int dtype, const void *g, int ldg, int col0, c
     {
         static int mfma = -1;
         if (mfma < 0) { const char *e = getenv("TC_HEAD_MFMA"); mfma = e ? atoi(e) != 0 : 1; }
-        if (mfma && dtype == TC_BF16 && (V == 10 || V == 3) && E % 32 == 0 && ldg % 8 == 0 && col0 % 8 == 0 && M >= 16) {
+        if (mfma && dtype == TC_BF16 && (V == 10 || V == 3) && E % 32 == 0 && ldg % 8 == 0 && col0 % 8 == 0 && M >= 16 &&
+            tc_aligned16(g) && tc_aligned16(gamma) && tc_aligned16(beta) && tc_aligned16(W)) {
             const int lds = (E / 32) * 2 * 1024 + 128;
             const int nblk = (M + 15) / 16;
             const dim3 mgrid((nblk + 3) / 4 < 768 ? (nblk + 3) / 4 : 768);
