@@ -1553,16 +1553,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
                 if constexpr (u < kIssued) {
                     constexpr int nq = q >> 4, mi = (q >> 1) & 7;
                     const unsigned off = ((unsigned)(tm * BM + mi_off<2>(mi)) * (unsigned)p.ldo + (unsigned)(tn * BN + nq * 128)) * 2u;
-#ifdef TC_ABL_RESLDS
-                    // measurement build: the same bytes by LDS-DMA into a dump area (no register return; results are garbage)
-                    tc_blds16(tc_buffer_rsrc((q & 1) ? p.res_lo : reinterpret_cast<const char *>(p.residual)), res_voff, off,
-                              smem + STEP_OFF + (wid & 3) * 1024);
-#elif defined(TC_ABL_RESL2)
-                    // measurement build: every request of the kernel reads the plane's first 16 x 256 block (cache hits)
-                    tc_buf_load16_slot<(JJ & 1) * 4 + u>(rq[JJ & 1][u], (q & 1) ? rsrc_lo : rsrc_hi, res_voff, 0u * off);
-#else
                     tc_buf_load16_slot<(JJ & 1) * 4 + u>(rq[JJ & 1][u], (q & 1) ? rsrc_lo : rsrc_hi, res_voff, off);
-#endif
                 }
             };
 
@@ -1747,10 +1738,10 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
                     constexpr int u = decltype(uc)::value, q = JP * STREAM + u;
                     if constexpr (u < STREAM && q < 32 && (q & 1) == decltype(plane_c)::value) {
                         constexpr int nq = q >> 4, mi = (q >> 1) & 7;
-#ifndef TC_ABL_NORESMFMA
+                        // (these reads are what keeps the named destination registers of the loads above live:
+                        // without a reader the allocator hands them to addresses while the loads are in flight)
                         tc_mfma_bf16_slot<(JP & 1) * 4 + u>(acc[nq * 2][mi], s0f, rq[JP & 1][u]);
                         tc_mfma_bf16_slot<(JP & 1) * 4 + u>(acc[nq * 2 + 1][mi], s1f, rq[JP & 1][u]);
-#endif
                     }
                 };
                 res_add(std::integral_constant<int, 0>{}, I0{}); res_add(std::integral_constant<int, 1>{}, I0{});
