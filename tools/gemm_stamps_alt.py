@@ -69,7 +69,7 @@ for name in names:
         print(f"{name} group {grp}: in-kernel clock {ghz:.2f} GHz  tiles/WG {tiles:.1f} total {m[25]:.0f} per tile {m[25] / tiles:.0f}  epilogue/tile {m[24] / tiles:.0f}  "
               f"k-tile by position {per}", flush=True)
         if float(ph.sum()) > 0:          # library built with -DTC_GEMM_PHASES: a tile's first and last k-tile
-            for c, cname in enumerate(("first", "last")):
+            for c, cname in enumerate(os.environ.get("TC_PH_NAMES", "first,last").split(",")):
                 v = (ph[:, grp, c].mean(0) / tiles).tolist()
                 print(f"    {cname:5s} k-tile: issue+epilogue {v[0]:.0f} | reads {v[1]:.0f} | bar {v[2]:.0f} | mfma+bar {v[3]:.0f} || "
                       f"p1: {v[4]:.0f} {v[5]:.0f} {v[6]:.0f} | p2: {v[7]:.0f} {v[8]:.0f} {v[9]:.0f} | p3: {v[10]:.0f} {v[11]:.0f} {v[12]:.0f}", flush=True)

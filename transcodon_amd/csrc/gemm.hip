@@ -1488,19 +1488,26 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();   // 100 MHz: gives the clock the kernel ran at
 #endif
 #ifdef TC_GEMM_PHASES
-    // Hand-over profile: only a tile's first and last k-tile carry stamps (13 points each); slots
-    // [first / last][interval] accumulate shader clocks between consecutive points.
+    // Hand-over profile: only two k-tile positions of a tile carry stamps (13 points each; the first and the
+    // last unless -DTC_PH_KA= / -DTC_PH_KB= name others); slots [A / B][interval] accumulate shader clocks
+    // between consecutive points.
+#ifndef TC_PH_KA
+#define TC_PH_KA 0
+#endif
+#ifndef TC_PH_KB
+#define TC_PH_KB (p.nk - 1)
+#endif
     unsigned c_ph[2][13] = {};
     unsigned long long ph_t = 0;
 #define TC_PH(i)                                                                              \
     do {                                                                                      \
-        if (kt == 0 || kt == p.nk - 1) {                                                      \
+        if (kt == TC_PH_KA || kt == TC_PH_KB) {                                               \
             const unsigned long long now__ = __builtin_amdgcn_s_memtime();                    \
-            c_ph[kt == 0 ? 0 : 1][i] += (unsigned)(now__ - ph_t);                             \
+            c_ph[kt == TC_PH_KA ? 0 : 1][i] += (unsigned)(now__ - ph_t);                      \
             ph_t = now__;                                                                     \
         }                                                                                     \
     } while (0)
-#define TC_PH_START() do { if (kt == 0 || kt == p.nk - 1) ph_t = __builtin_amdgcn_s_memtime(); } while (0)
+#define TC_PH_START() do { if (kt == TC_PH_KA || kt == TC_PH_KB) ph_t = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TC_PH(i)
 #define TC_PH_START()
