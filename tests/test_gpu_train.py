@@ -424,7 +424,7 @@ def test_batched_transposes_equal_torch(dtype):
     from transcodon_amd import _lib
     lib = _lib.load()
     g = torch.Generator(device=DEV).manual_seed(3)
-    shapes = [(768, 768), (2304, 768), (3072, 768), (768, 3072), (64, 64), (128, 192)] * 9      # 54 > one launch's 48
+    shapes = [(768, 768), (2304, 768), (3072, 768), (768, 3072), (64, 64), (128, 192)] * 12      # 72 > one launch's 64
     src = [torch.randn(r, c, device=DEV, generator=g).to(dtype) for r, c in shapes]
     dst = [torch.full((c, r), 7.0, device=DEV, dtype=dtype) for r, c in shapes]
     n = len(shapes)

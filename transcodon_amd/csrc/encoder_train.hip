@@ -185,7 +185,7 @@ void *wt_of_head(const tc_encoder_desc *d, const TrainWs &w, int head) {
     const size_t E = d->E, F = d->F, esz = d->dtype == TC_BF16 ? 2 : 4;
     return w.wt_all + ((size_t)d->num_layers * (4 * E * E + 2 * E * F) + (size_t)head * E * E) * esz;
 }
-// one launch (per 48 matrices) for all of them
+// one launch (per 64 matrices) for all of them
 int transpose_weights(const tc_encoder_desc *d, const TrainWs &w, void *stream) {
     constexpr int kMost = 4 * kMaxLayers + 2;
     static_assert(kMost <= 512, "descriptor arrays on the stack");

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI *__restrict__ i
 // step, so all of them are transposed by one launch per backward pass instead of one small launch each
 // (a 768 x 768 matrix is 144 tiles: such launches are latency, not bandwidth).  Entry e: src [rows, cols]
 // dense -> dst [cols, rows] dense, rows and cols multiples of 64; 64 x 64 tiles, 16 bytes per lane both ways.
-constexpr int kTbMax = 48;
+constexpr int kTbMax = 64;       // 1.8 KB of kernel arguments
 struct TransposeBatch {
     const void *src[kTbMax];
     void *dst[kTbMax];
