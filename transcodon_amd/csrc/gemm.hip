@@ -462,8 +462,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tc_out_rsrc(const void *base, 
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)((unsigned)rows * (unsigned)ld * (unsigned)esz),
                                              0x00020000);
 }
+#ifndef TC_LOADA_AUX
+#define TC_LOADA_AUX 0
+#endif
+#ifndef TC_LOADW_AUX
+#define TC_LOADW_AUX 0
+#endif
+#ifndef TC_STORE_AUX
+#define TC_STORE_AUX 0          // cache policy bits of the epilogue stores (2 = nt: streaming lines)
+#endif
 __device__ __forceinline__ void tc_bstore16(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, unsigned byte_off) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, 0, TC_STORE_AUX);
 }
 
 // Epilogue of one wave tile.  Phase 1: arithmetic in place (its table loads are not queued
@@ -1267,13 +1276,18 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
 #if TC_GEMM_BUFLOAD
     const __amdgpu_buffer_rsrc_t rsrc_a = tc_buffer_rsrc(p.A), rsrc_w = tc_buffer_rsrc(p.W);
 #endif
-    auto stage_half = [&](int slot_off, const char *base, const unsigned (&src)[2], unsigned koff) {
+    // (cache policy of the operand loads: TC_LOADA_AUX / TC_LOADW_AUX, 2 = nt, streaming lines)
+    using IsA = std::integral_constant<int, 1>;
+    using IsW = std::integral_constant<int, 0>;
+    auto stage_half = [&](auto which, int slot_off, const char *base, const unsigned (&src)[2], unsigned koff) {
 #ifndef TC_ABL_NODMA
         char *dst = smem + slot_off + wid * 2048;
 #if TC_GEMM_BUFLOAD
-        const __amdgpu_buffer_rsrc_t rsrc = base == p.A ? rsrc_a : rsrc_w;
-        tc_blds16(rsrc, src[0], koff, dst);
-        tc_blds16(rsrc, src[1], koff, dst + 1024);
+        constexpr bool kIsA = decltype(which)::value == 1;
+        const __amdgpu_buffer_rsrc_t rsrc = kIsA ? rsrc_a : rsrc_w;
+        constexpr int kAux = kIsA ? TC_LOADA_AUX : TC_LOADW_AUX;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, TC_LDS_PTR(dst), 16, (int)src[0], (int)koff, 0, kAux);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, TC_LDS_PTR(dst + 1024), 16, (int)src[1], (int)koff, 0, kAux);
 #else
         glds16(base + (src[0] + koff), dst);
         glds16(base + (src[1] + koff), dst + 1024);
@@ -1396,13 +1410,13 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             glds16(reinterpret_cast<const char *>(tab + ((lane & 16) ? 80 : 16) * 32 + (lane & 7) * 4), step_slot);
         }
     }
-    stage_half(SLOT_B0, p.W, b0_src, 0);
-    stage_half(SLOT_A0, p.A, a0_src, 0);
-    stage_half(SLOT_B1, p.W, b1_src, 0);
-    stage_half(SLOT_A1, p.A, a1_src, 0);
-    stage_half(DBUF_BYTES + SLOT_B0, p.W, b0_src, 128);
-    stage_half(DBUF_BYTES + SLOT_A0, p.A, a0_src, 128);
-    stage_half(DBUF_BYTES + SLOT_B1, p.W, b1_src, 128);
+    stage_half(IsW{}, SLOT_B0, p.W, b0_src, 0);
+    stage_half(IsA{}, SLOT_A0, p.A, a0_src, 0);
+    stage_half(IsW{}, SLOT_B1, p.W, b1_src, 0);
+    stage_half(IsA{}, SLOT_A1, p.A, a1_src, 0);
+    stage_half(IsW{}, DBUF_BYTES + SLOT_B0, p.W, b0_src, 128);
+    stage_half(IsA{}, DBUF_BYTES + SLOT_A0, p.A, a0_src, 128);
+    stage_half(IsW{}, DBUF_BYTES + SLOT_B1, p.W, b1_src, 128);
     int c1_tile = 0, c1_k = 1;                   // next A1 to stage
     int c2_tile = 0, c2_k = 2;                   // next B0 A0 B1 to stage
     if (c2_k == p.nk) { c2_k = 0; c2_tile = 1; if (c2_tile < my_count) { advance(c2m, c2n, c2i); set_c2(); } }
@@ -1625,7 +1639,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
                 if (kt == 1 && t > 0 && p.row_acc) flush_row_sums<true>(p, smem + ROPE_OFF + ((t - 1) & 1) * 8192, ptm);
             }
             if (c1_tile < my_count) {
-                stage_half(nxt + SLOT_A1, p.A, a1_src, (unsigned)c1_k * 128u);
+                stage_half(IsA{}, nxt + SLOT_A1, p.A, a1_src, (unsigned)c1_k * 128u);
                 if (++c1_k == p.nk) { c1_k = 0; if (++c1_tile < my_count) { advance(c1m, c1n, c1i); set_c1(); } }
             }
             if constexpr (kQuarters) {
@@ -1655,7 +1669,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             // ---- phase 1 ----
             const bool more = c2_tile < my_count;
             const unsigned koff2 = (unsigned)c2_k * 128u;
-            if (more) stage_half(cur + SLOT_B0, p.W, b0_src, koff2);
+            if (more) stage_half(IsW{}, cur + SLOT_B0, p.W, b0_src, koff2);
             if constexpr (kQuarters) {
                 if (after) finish_quarter(ptm, ptn, I0{}, I1{});
             }
@@ -1666,7 +1680,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             math(0, 1);                            // ends with the hand-over barrier
             TC_PH(6);
             // ---- phase 2 ----
-            if (more) stage_half(cur + SLOT_A0, p.A, a0_src, koff2);
+            if (more) stage_half(IsA{}, cur + SLOT_A0, p.A, a0_src, koff2);
             if constexpr (kQuarters) {
                 if (after) finish_quarter(ptm, ptn, I1{}, I1{});
             }
@@ -1683,7 +1697,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             if constexpr (kQuarters) {
                 // the last quarter's stores go out before the wait, so that the count below (every
                 // operation younger than this k-tile's A1) is the same as with one epilogue block
-                if (after && more) stage_half(cur + SLOT_B1, p.W, b1_src, koff2);
+                if (after && more) stage_half(IsW{}, cur + SLOT_B1, p.W, b1_src, koff2);
                 if (after) finish_quarter(ptm, ptn, I1{}, I0{});
             }
             // Streamed residual: this k-tile's requests and the selection fragments for the pieces that are about to
@@ -1703,7 +1717,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (more) {
-                if (!(kQuarters && after)) stage_half(cur + SLOT_B1, p.W, b1_src, koff2);
+                if (!(kQuarters && after)) stage_half(IsW{}, cur + SLOT_B1, p.W, b1_src, koff2);
                 if (++c2_k == p.nk) { c2_k = 0; if (++c2_tile < my_count) { advance(c2m, c2n, c2i); set_c2(); } }
                 // (kIssued: this k-tile's residual plane pieces, younger than its A1 as well)
                 if (after && prev_full) {
