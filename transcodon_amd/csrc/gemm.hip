@@ -471,9 +471,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tc_out_rsrc(const void *base, 
 #ifndef TC_STORE_AUX
 #define TC_STORE_AUX 0          // cache policy bits of the epilogue stores (2 = nt: streaming lines)
 #endif
+template <int AUX = TC_STORE_AUX>
 __device__ __forceinline__ void tc_bstore16(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, unsigned byte_off) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, 0, TC_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, 0, AUX);
 }
+// The rotated q/k/v rows are written as streaming (nt) lines: 600 MB per launch that the attention kernel reads
+// front to back long after they have left every cache, and that otherwise push the weight panels out of L2 while
+// the product is still running (-1.5 ... -2.5 % per launch; the other epilogues gain nothing or feed a consumer
+// that still finds its input in the Infinity Cache).
+#ifndef TC_QKV_STORE_AUX
+#define TC_QKV_STORE_AUX 2
+#endif
 
 // Epilogue of one wave tile.  Phase 1: arithmetic in place (its table loads are not queued
 // behind any store); phase 2: all stores.
@@ -778,7 +786,7 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
                     w[2] = tc_pack_bf16(v2[0], v2[1]);
                     w[3] = tc_pack_bf16(v2[2], v2[3]);
                     w = exchange(w);
-                    tc_bstore16(rs_out, w, (orow + ni_off<LAY>(ni)) * 2u);
+                    tc_bstore16<EPI == TC_EPI_QKV_ROPE ? TC_QKV_STORE_AUX : TC_STORE_AUX>(rs_out, w, (orow + ni_off<LAY>(ni)) * 2u);
                 }
             } else if constexpr (SPLIT) {
                 // result as two bf16 planes, hi = bf16(v), lo = bf16(v - hi): one 16-byte store each
