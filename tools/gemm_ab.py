@@ -25,6 +25,8 @@ def load(path):
     res, args = _lib._SIGNATURES["tc_gemm"]
     lib.tc_gemm.restype, lib.tc_gemm.argtypes = res, args
     lib.tc_last_error.restype = C.c_char_p
+    res, args = _lib._SIGNATURES["tc_gemm_train"]
+    lib.tc_gemm_train.restype, lib.tc_gemm_train.argtypes = res, args
     if hasattr(lib, "tc_gemm_residual_split"):
         res, args = _lib._SIGNATURES["tc_gemm_residual_split"]
         lib.tc_gemm_residual_split.restype, lib.tc_gemm_residual_split.argtypes = res, args
@@ -73,6 +75,9 @@ def main():
               # the new build keeps the residual stream as two bf16 planes, updated in place
               "out_split": (x, E, E, E, _lib.EPI_BIAS_RESIDUAL, E, True),
               "fc2_split": (mid, F + 64, E, F, _lib.EPI_BIAS_RESIDUAL, E, True)}
+    # training products (tc_gemm_train): GELU with the saved pre-activation, and the dGELU data gradient
+    shapes["fc1_save"] = (x, E, F, E, _lib.EPI_BIAS_GELU_SAVE, F + 64, False)
+    shapes["fc2_dgelu"] = (x, E, F, E, _lib.EPI_DGELU, F + 64, False)
     # the new build runs these with a LayerNorm folded in (row pairs + column sums in the epilogue)
     shapes["qkv_fold"] = shapes["qkv"]
     shapes["fc1_fold"] = shapes["fc1"]
@@ -80,6 +85,7 @@ def main():
     plane_hi = torch.randn(M, E, device=dev, generator=g).bfloat16()
     plane_lo = (torch.randn(M, E, device=dev, generator=g) * 1e-3).bfloat16()
     copy16 = torch.empty(M, E, device=dev, dtype=torch.bfloat16)
+    pre = torch.randn(M, F + 64, device=dev, generator=g).bfloat16()      # saved pre-activation (written or read)
     row_acc = torch.zeros(M, 2, device=dev, dtype=torch.int64)
     for name in a.only.split(","):
         A, lda, N, K, epi, ldo, f32 = shapes[name]
@@ -101,6 +107,13 @@ def main():
             if name.endswith("_split") and (k == "new" or hasattr(libs[k], "tc_gemm_residual_split")):
                 rc = libs[k].tc_gemm_residual_split(1, A.data_ptr(), lda, w.data_ptr(), b.data_ptr(), planes[k][0].data_ptr(),
                                                     planes[k][1].data_ptr(), row_accs[k].data_ptr(), ldo, M, N, K, strm)
+                assert rc == 0, libs[k].tc_last_error()
+                return
+            if epi in (_lib.EPI_BIAS_GELU_SAVE, _lib.EPI_DGELU):
+                save = epi == _lib.EPI_BIAS_GELU_SAVE
+                rc = libs[k].tc_gemm_train(1, epi, A.data_ptr(), lda, w.data_ptr(), b.data_ptr() if save else None,
+                                           None if save else pre.data_ptr(), outs[k].data_ptr(), pre.data_ptr() if save else None,
+                                           ldo, M, N, K, 1, strm)
                 assert rc == 0, libs[k].tc_last_error()
                 return
             rc = libs[k].tc_gemm(1, epi, A.data_ptr(), lda, w.data_ptr(), b.data_ptr(), res.data_ptr() if f32 else None,

@@ -475,12 +475,26 @@ template <int AUX = TC_STORE_AUX>
 __device__ __forceinline__ void tc_bstore16(__amdgpu_buffer_rsrc_t rsrc, u32x4 v, unsigned byte_off) {
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)byte_off, 0, AUX);
 }
-// The rotated q/k/v rows are written as streaming (nt) lines: 600 MB per launch that the attention kernel reads
-// front to back long after they have left every cache, and that otherwise push the weight panels out of L2 while
-// the product is still running (-1.5 ... -2.5 % per launch; the other epilogues gain nothing or feed a consumer
-// that still finds its input in the Infinity Cache).
+// Cache policy per result (0 = default, 2 = nt, streaming lines).  Measured inside the whole step (kernel traces of
+// two builds on one box): streaming q/k/v rows, fc1 results or data-gradient results make their own product 5-15 %
+// slower there, although the same product alone, launched back to back, gains 2-7 % from them.
+#ifndef TC_BIAS_STORE_AUX
+#define TC_BIAS_STORE_AUX 0
+#endif
+#ifndef TC_DGELU_STORE_AUX
+#define TC_DGELU_STORE_AUX 0
+#endif
+#ifndef TC_SAVE_STORE_AUX
+#define TC_SAVE_STORE_AUX 0      // GELU output of the training forward's fc1
+#endif
 #ifndef TC_QKV_STORE_AUX
-#define TC_QKV_STORE_AUX 2
+#define TC_QKV_STORE_AUX 0
+#endif
+#ifndef TC_SAVE_U_STORE_AUX
+#define TC_SAVE_U_STORE_AUX 0    // pre-activation kept for the backward pass
+#endif
+#ifndef TC_LO_STORE_AUX
+#define TC_LO_STORE_AUX 0        // lo plane of the residual stream (read again two products later)
 #endif
 
 // Epilogue of one wave tile.  Phase 1: arithmetic in place (its table loads are not queued
@@ -547,7 +561,7 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
                     w[3] = tc_pack_bf16(v2[2], v2[3]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) w[e] = (unsigned)__builtin_amdgcn_ds_bpermute(pull, (int)w[e]);
-                    tc_bstore16(rs2, w, (orow + ni_off<LAY>(ni)) * 2u);
+                    tc_bstore16<TC_SAVE_U_STORE_AUX>(rs2, w, (orow + ni_off<LAY>(ni)) * 2u);
                 }
             }
         } else {
@@ -786,7 +800,7 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
                     w[2] = tc_pack_bf16(v2[0], v2[1]);
                     w[3] = tc_pack_bf16(v2[2], v2[3]);
                     w = exchange(w);
-                    tc_bstore16<EPI == TC_EPI_QKV_ROPE ? TC_QKV_STORE_AUX : TC_STORE_AUX>(rs_out, w, (orow + ni_off<LAY>(ni)) * 2u);
+                    tc_bstore16<EPI == TC_EPI_QKV_ROPE ? TC_QKV_STORE_AUX : EPI == TC_EPI_BIAS_GELU_SAVE ? TC_SAVE_STORE_AUX : EPI == TC_EPI_DGELU ? TC_DGELU_STORE_AUX : EPI == TC_EPI_BIAS ? TC_BIAS_STORE_AUX : TC_STORE_AUX>(rs_out, w, (orow + ni_off<LAY>(ni)) * 2u);
                 }
             } else if constexpr (SPLIT) {
                 // result as two bf16 planes, hi = bf16(v), lo = bf16(v - hi): one 16-byte store each
@@ -809,7 +823,7 @@ __device__ __forceinline__ void epilogue256(const GemmParams &p, f32x4 (&acc)[4]
                     h = exchange(h);
                     l = exchange(l);
                     tc_bstore16(rs_out2, h, (orow + ni_off<LAY>(ni)) * 2u);
-                    tc_bstore16(rs_lo, l, (orow + ni_off<LAY>(ni)) * 2u);
+                    tc_bstore16<TC_LO_STORE_AUX>(rs_lo, l, (orow + ni_off<LAY>(ni)) * 2u);
                 }
                 if (stat_lds) put_row_sums(stat_lds, wm, wn, mi_off<LAY>(mi), frow, fgrp, s1, s2);
             } else {
