@@ -9,7 +9,8 @@ for i in range(1, n + 1):
     for rep in (1, 2):
         with open(os.path.join(here, "..", "gpurun_out", f"trace_{tag}_{i}_{rep}.csv")) as fh:
             cols[(i, rep)] = {r["kernel"][:72]: float(r["total_ms"]) for r in csv.DictReader(fh)}
-keys = sorted(cols[(1, 1)], key=lambda k: -cols[(1, 1)][k])[:16]
+allk = set().union(*[set(c) for c in cols.values()])
+keys = sorted(allk, key=lambda k: -max(c.get(k, 0.0) for c in cols.values()))[:int(sys.argv[3]) if len(sys.argv) > 3 else 18]
 print("%-72s" % "kernel (total ms)" + "".join("  b%d.%d   " % c for c in sorted(cols)))
 for k in keys:
     print("%-72s" % k + "".join("%8.2f " % cols[c].get(k, 0.0) for c in sorted(cols)))
