@@ -468,6 +468,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tc_out_rsrc(const void *base, 
 #ifndef TC_LOADW_AUX
 #define TC_LOADW_AUX 0
 #endif
+#ifndef TC_GEMM_REV
+#define TC_GEMM_REV 1           // fc1 walks its row panels downwards (see kRev)
+#endif
 #ifndef TC_STORE_AUX
 #define TC_STORE_AUX 0          // cache policy bits of the epilogue stores (2 = nt: streaming lines)
 #endif
@@ -1232,9 +1235,16 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     const int base1 = p.tiles_m * w0;                       // linear index of the second group's first tile
     const int sm0 = per_class / w0, sn0 = per_class - sm0 * w0;
     const int sm1 = per_class / w1s, sn1 = per_class - sm1 * w1s;
+    // kRev: the row panels are walked from the last one down (tm is always the panel's real index).  A product
+    // that starts where its producer has just stopped finds the tail of its input still in the Infinity Cache:
+    // fc1 runs against the direction of the residual product before it, and leaves its own tail at the low rows,
+    // where fc2 starts.
+    constexpr bool kRev = TC_GEMM_REV && (EPI == TC_EPI_BIAS_GELU || EPI == TC_EPI_BIAS_GELU_SAVE) && !PANELS;
+    constexpr int kDir = kRev ? -1 : 1;
     auto locate = [&](int idx, int &tm, int &tn) {
         if (idx < base1) { tm = idx / w0; tn = idx - tm * w0; }
         else { const int l = idx - base1; tm = l / w1s; tn = w0 + l - tm * w1s; }
+        if constexpr (kRev) tm = p.tiles_m - 1 - tm;
     };
     const int tile0 = first + j;
     int tm0, tn0;
@@ -1243,10 +1253,10 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         const int nidx = idx + per_class;
         if (idx < base1) {
             if (nidx >= base1) locate(nidx, tm, tn);
-            else { tn += sn0; tm += sm0; if (tn >= w0) { tn -= w0; ++tm; } }
+            else { tn += sn0; tm += kDir * sm0; if (tn >= w0) { tn -= w0; tm += kDir; } }
         } else {
-            tn += sn1; tm += sm1;
-            if (tn >= p.tiles_n) { tn -= w1s; ++tm; }
+            tn += sn1; tm += kDir * sm1;
+            if (tn >= p.tiles_n) { tn -= w1s; tm += kDir; }
         }
         idx = nidx;
     };
