@@ -1181,9 +1181,6 @@ constexpr bool piecewise_epilogue(int epi) {
     } while (0)
 #endif
 
-#ifndef TC_GEMM_EARLY
-#define TC_GEMM_EARLY 0
-#endif
 
 template <typename T, int EPI, bool FOLD = false, bool PANELS = false, int STREAM = 0>
 __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
@@ -1191,7 +1188,6 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
     static_assert(STREAM == 0 || STREAM == 2 || STREAM == 3, "plane pieces per k-tile");
     using namespace k256x;
     static_assert(!PANELS || (EPI == TC_EPI_QKV_ROPE && FOLD), "row panel lists: folded q/k/v product only");
-    constexpr int kEarly = TC_GEMM_EARLY;      // MFMAs of a phase issued after its hand-over barrier
     static_assert(sizeof(T) == 2, "bf16 only");
     // Epilogues that read nothing from global memory (bias comes through LDS) run inside phase 0
     // of the next tile's first k-tile, after that phase's LDS-DMA issue and before its LDS reads:
@@ -1476,31 +1472,12 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // Measured and left off (TC_GEMM_PIECES=1 builds it): the quarters make the epilogue 4-11 % SLOWER
-    // on the K = 768 shapes.  A wave's epilogue is bound by the latency of its exchange / store chains,
-    // not by vector issue: the two waves of a SIMD hide each other's latency when they run it side by
-    // side, which a quarter running beside the partner's MFMAs cannot.
-#ifndef TC_GEMM_PIECES
-#define TC_GEMM_PIECES 0
-#endif
-    // Quarter (mq, nq) of the previous tile's epilogue: run in the load slot of the phase whose MFMAs
-    // use that quarter's accumulators next, while the other wave group multiplies.  Spread over the
-    // four phases of a tile's first k-tile instead of one block with the matrix pipe idle.
-    auto finish_quarter = [&](int tm, int tn, auto mq_c, auto nq_c) {
-        constexpr int mq = decltype(mq_c)::value, nq = decltype(nq_c)::value;
-        const int mrow0 = tm * BM + wr * 64 + frow, ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);
-        epilogue256<T, EPI, kLay, 4 * mq, 4 * mq + 4, 2 * nq, 2 * nq + 2, EPI == TC_EPI_QKV_ROPE || kGeluTable>(
-            p, acc, tm, tn, mrow0, ncol0, wr, wc, frow, fgrp, lds_bias ? bias_slot : nullptr,
-            kGeluTable ? smem + ROPE_OFF : rope_slot, step_slot);
-#pragma unroll
-        for (int ni = 2 * nq; ni < 2 * nq + 2; ++ni)
-#pragma unroll
-            for (int mi = 4 * mq; mi < 4 * mq + 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_sched_barrier(0);
-    };
+    // (The deferred epilogue as four quarters, each in the load slot of the phase whose MFMAs use that quarter's
+    // accumulators next, was measured 4-11 % slower on the K = 768 shapes: a wave's epilogue is bound by the latency
+    // of its exchange / store chains, which the two waves of a SIMD hide for each other when they run it side by
+    // side and a quarter beside the partner's MFMAs cannot.)
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    constexpr bool kQuarters = kPiece && TC_GEMM_PIECES && EPI != TC_EPI_BIAS_GELU_SAVE;
     // epilogue of tile `local` (bias from this wave's LDS copy), accumulators back to zero
     auto finish_tile = [&](int tm, int tn, int parity) __attribute__((always_inline)) {
         const int mrow0 = tm * BM + wr * 64 + frow, ncol0 = tn * BN + wc * 32 + fgrp * (kLay == 2 ? 8 : 4);
@@ -1611,10 +1588,10 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             };
 
             // A phase's 16 MFMAs, then the barrier that hands the matrix pipe to the other wave of the SIMD.
-            // TC_GEMM_EARLY = n enters that barrier n MFMAs before the end of the turn.  On bare MFMA turns that
-            // removes the wake-up gap of the released wave (tools/ubench/mfma_handover.hip: 256 -> 217 ns per 32
-            // MFMAs); here it costs 3-9 %, because the phase is bound by the load slot of the wave that is not
-            // multiplying, and the late MFMAs delay the start of that slot.
+            // (Entering that barrier a few MFMAs before the end of the turn removes the wake-up gap of the released
+            // wave on bare MFMA turns, tools/ubench/mfma_handover.hip: 256 -> 217 ns per 32 MFMAs; here it cost 3-9 %,
+            // because the phase is bound by the load slot of the wave that is not multiplying, and the late MFMAs
+            // delay the start of that slot.)
             auto math = [&](int mq, int nq, bool hand_over = true) {
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1623,13 +1600,12 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
                     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            if (kEarly > 0 && (ks * 2 + nb) * 4 + i == 16 - kEarly) TC_XBAR();
                             acc[nq * 2 + nb][mq * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                 __builtin_bit_cast(bf16x8, bq[nq][nb][ks]), __builtin_bit_cast(bf16x8, af[i][ks]),
                                 acc[nq * 2 + nb][mq * 4 + i], 0, 0, 0);
                         }
                 __builtin_amdgcn_s_setprio(0);
-                if (kEarly == 0 && hand_over) TC_XBAR();
+                if (hand_over) TC_XBAR();
             };
             auto read_b = [&](int nq) {
 #pragma unroll
@@ -1674,9 +1650,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
                 stage_half(IsA{}, nxt + SLOT_A1, p.A, a1_src, (unsigned)c1_k * 128u);
                 if (++c1_k == p.nk) { c1_k = 0; if (++c1_tile < my_count) { advance(c1m, c1n, c1i); set_c1(); } }
             }
-            if constexpr (kQuarters) {
-                if (after) finish_quarter(ptm, ptn, I0{}, I0{});
-            } else if constexpr (kPiece) {
+            if constexpr (kPiece) {
                 if (after) {
                     TC_STAMP(e0);
                     finish_tile(ptm, ptn, (t - 1) & 1);
@@ -1702,9 +1676,6 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             const bool more = c2_tile < my_count;
             const unsigned koff2 = (unsigned)c2_k * 128u;
             if (more) stage_half(IsW{}, cur + SLOT_B0, p.W, b0_src, koff2);
-            if constexpr (kQuarters) {
-                if (after) finish_quarter(ptm, ptn, I0{}, I1{});
-            }
             read_b(1);
             TC_PH(4);
             TC_XBAR();
@@ -1713,9 +1684,6 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             TC_PH(6);
             // ---- phase 2 ----
             if (more) stage_half(IsA{}, cur + SLOT_A0, p.A, a0_src, koff2);
-            if constexpr (kQuarters) {
-                if (after) finish_quarter(ptm, ptn, I1{}, I1{});
-            }
             read_a(1);
             TC_PH(7);
             TC_XBAR();
@@ -1726,12 +1694,6 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
             // The wait leaves in flight what was issued after this k-tile's A1: three half-tiles,
             // plus, in a tile's first k-tile, the previous tile's stores (when none of its rows
             // was masked, so that every store instruction was issued; the counter holds 63).
-            if constexpr (kQuarters) {
-                // the last quarter's stores go out before the wait, so that the count below (every
-                // operation younger than this k-tile's A1) is the same as with one epilogue block
-                if (after && more) stage_half(IsW{}, cur + SLOT_B1, p.W, b1_src, koff2);
-                if (after) finish_quarter(ptm, ptn, I1{}, I0{});
-            }
             // Streamed residual: this k-tile's requests and the selection fragments for the pieces that are about to
             // be added go out here, in the lightest load slot of the four (two staging pieces, no fragment reads)
             f32x4 s0f = {0.f, 0.f, 0.f, 0.f}, s1f = s0f;
@@ -1749,7 +1711,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (more) {
-                if (!(kQuarters && after)) stage_half(IsW{}, cur + SLOT_B1, p.W, b1_src, koff2);
+                stage_half(IsW{}, cur + SLOT_B1, p.W, b1_src, koff2);
                 if (++c2_k == p.nk) { c2_k = 0; if (++c2_tile < my_count) { advance(c2m, c2n, c2i); set_c2(); } }
                 // (kIssued: this k-tile's residual plane pieces, younger than its A1 as well)
                 if (after && prev_full) {
@@ -1864,7 +1826,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const GemmParams p) {
         // After a tile's last phase row group 0 waits for row group 1, so that both run the
         // deferred epilogue at the same time (each hides the other's LDS and exchange latency)
         // instead of one after the other; group 1 falls half a phase behind again right after it.
-        if constexpr (kPiece && !kQuarters) {
+        if constexpr (kPiece) {
             if (wr == 0) TC_XBAR();
         }
         ptm = tm;
