@@ -29,10 +29,10 @@
 extern "C" {
 #endif
 
-/* Changes whenever a struct layout or a signature of this header changes; a caller built against another
+/* Changes whenever a struct layout or a signature of this header changes or an entry point is added; a caller built against another
  * value must not call into the library.  tc_struct_bytes lets a binding that restates the structs (ctypes)
  * verify its own layout: which = 0 tc_layer_weights, 1 tc_encoder_desc, 2 tc_layer_grads, 3 tc_encoder_grads. */
-#define TC_VERSION 130
+#define TC_VERSION 131
 
 /* status codes */
 #define TC_OK 0

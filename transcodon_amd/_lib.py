@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TC_LIB_PATH points at another build of the same library (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("TC_LIB_PATH") or os.path.join(_HERE, "csrc", "libtranscodon_hip.so")
 
-ABI_VERSION = 130          # TC_VERSION of include/transcodon_hip.h this binding restates
+ABI_VERSION = 131          # TC_VERSION of include/transcodon_hip.h this binding restates
 TC_F32, TC_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_QKV_ROPE = 0, 1, 2, 3
 EPI_PLAIN_F32, EPI_BIAS_GELU_SAVE, EPI_DGELU = 4, 5, 6
