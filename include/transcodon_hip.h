@@ -397,7 +397,8 @@ int tc_attn_bwd_static(int dtype, const void *qkv, int ldq, const uint64_t *key_
  *                      then rounded in another order than tc_gemm(TC_EPI_BIAS_RESIDUAL) rounds it (the pair agrees
  *                      with that product to 2^-15 of the value plus 2^-16 absolute, the hi plane differs from its
  *                      bf16 rounding in fewer than 2 elements in 1000, by one bf16 step).  Environment
- *                      TC_RES_STREAM=0 keeps the load-ahead form for every K.  M * ldo * 2 must stay below 4 GiB.
+ *                      TC_RES_STREAM=0 keeps the load-ahead form for every K, =2 streams two plane pieces per k-tile
+ *                      instead of three (another rounding order within the same bound).  M * ldo * 2 must stay below 4 GiB.
  * tc_layernorm_fwd_split  tc_layernorm_fwd reading the plane pair;  tc_split_to_f32: out[i] = hi[i] + lo[i].
  * tc_gemm_residual_ln  tc_gemm(TC_EPI_BIAS_RESIDUAL) that also writes out_bf16 [M,ldo] = bf16(out) and
  *                      adds, per row, the sum and the sum of squares of the bf16-rounded results to

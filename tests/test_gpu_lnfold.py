@@ -151,6 +151,53 @@ def test_residual_product_on_split_planes(Mr, K):
     assert torch.equal(ln, ops.layernorm(got, gamma, beta, 1e-5))
 
 
+def test_two_plane_pieces_per_ktile_give_the_same_planes(tmp_path):
+    """TC_RES_STREAM=2 (two plane pieces per k-tile over a tile's first sixteen k-tiles instead of three over eleven)
+    is the other instantiation of the streamed residual product.  A plane piece then joins its accumulator at
+    another k-tile, so the f32 sums round in another order: the pairs agree to the bound the streamed form states
+    against the plain product, hi differs at rounding ties only, and each form's row sums are those of its own hi
+    plane.  The switch is read once per process, hence the child processes."""
+    import os
+    import subprocess
+    import sys
+    lib = _lib.load()
+    K, Mr = 3072, 30 * 1024 + 700
+    g = torch.Generator().manual_seed(16)
+    a = torch.randn(Mr, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(E, K, generator=g) * 0.03).to(torch.bfloat16)
+    bias = 0.1 * torch.randn(E, generator=g)
+    x = torch.randn(Mr, E, generator=g) * 3 + 1.0
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    torch.save({"a": a, "w": w, "bias": bias, "hi": hi, "lo": lo}, tmp_path / "in.pt")
+    code = ("import torch, sys; from transcodon_amd import _lib; d = torch.load(sys.argv[1]); lib = _lib.load(); "
+            "t = {k: v.cuda() for k, v in d.items()}; acc = torch.zeros(t['hi'].shape[0], 2, dtype=torch.int64, device='cuda'); "
+            "_lib.check(lib.tc_gemm_residual_split(_lib.TC_BF16, t['a'].data_ptr(), t['a'].shape[1], t['w'].data_ptr(), "
+            "t['bias'].data_ptr(), t['hi'].data_ptr(), t['lo'].data_ptr(), acc.data_ptr(), t['hi'].shape[1], t['hi'].shape[0], "
+            "t['hi'].shape[1], t['a'].shape[1], torch.cuda.current_stream().cuda_stream), 'split'); "
+            "torch.cuda.synchronize(); torch.save({'hi': t['hi'].cpu(), 'lo': t['lo'].cpu(), 'acc': acc.cpu()}, sys.argv[2])")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, sw in (("three", {}), ("two", {"TC_RES_STREAM": "2"})):
+        env = dict(os.environ, PYTHONPATH=root, **sw)
+        subprocess.run([sys.executable, "-c", code, str(tmp_path / "in.pt"), str(tmp_path / f"{name}.pt")], check=True,
+                       env=env, timeout=240)
+        outs[name] = torch.load(tmp_path / f"{name}.pt")
+    pair = {n: o["hi"].float() + o["lo"].float() for n, o in outs.items()}
+    over = (pair["two"] - pair["three"]).abs() - 2.0 ** -15 * pair["three"].abs()
+    assert float(over.max()) <= 2.0 ** -16, float(over.max())
+    assert float((outs["two"]["hi"] != outs["three"]["hi"]).float().mean()) < 2e-3
+    for n, o in outs.items():
+        np.testing.assert_allclose((o["acc"][:, 0].double() / 2 ** 24).numpy(), o["hi"].double().sum(1).numpy(), rtol=0, atol=2e-3)
+    # and the default form in this process gives the same planes
+    t = {k: v.to(DEV) for k, v in {"a": a, "w": w, "bias": bias, "hi": hi, "lo": lo}.items()}
+    acc = torch.zeros(Mr, 2, dtype=torch.int64, device=DEV)
+    _lib.check(lib.tc_gemm_residual_split(_lib.TC_BF16, t["a"].data_ptr(), K, t["w"].data_ptr(), t["bias"].data_ptr(),
+                                          t["hi"].data_ptr(), t["lo"].data_ptr(), acc.data_ptr(), E, Mr, E, K, _stream()),
+               "tc_gemm_residual_split")
+    assert torch.equal(t["hi"].cpu(), outs["three"]["hi"]) and torch.equal(acc.cpu(), outs["three"]["acc"])
+
+
 def _rows_of(xb):
     x = xb.double()
     rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)
